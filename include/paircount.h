@@ -1,0 +1,145 @@
+/*
+ * paircount.h -- C ABI of the MI355X pair-counting library (libpaircount.so).
+ *
+ * The library replaces one path of Remmarg0rPA/particle-simulation: the
+ * spatial hash in src/hashmap.h and the counter-thread pool in src/main.c.
+ * The reference has no plugin or FFI layer; these entry points sit exactly on
+ * its two internal seams (the parser's per-point sink and the
+ * flatten()+count() call made by main()), so a C host binds them directly.
+ *
+ * Conventions: plain C types only; every function returns PC_OK (0) or a
+ * negative PC_ERR_* code and never throws or exits; pc_last_error() returns a
+ * thread-local message for the last failing call.  "device" pointers are HIP
+ * device addresses on the context's / current GPU; `stream` is a hipStream_t
+ * passed as void* (NULL = the default stream).  No function here falls back to
+ * the CPU: without a usable GPU they fail with PC_ERR_HIP.
+ */
+#ifndef PAIRCOUNT_H
+#define PAIRCOUNT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PC_OK 0
+#define PC_ERR_ARG (-1)     /* bad argument (null pointer, size, slab range)        */
+#define PC_ERR_HIP (-2)     /* a HIP runtime call failed / no GPU                   */
+#define PC_ERR_DOMAIN (-3)  /* a coordinate maps outside cells [0,400) on some axis */
+#define PC_ERR_NOMEM (-4)   /* host or device allocation failed                     */
+#define PC_ERR_STATE (-5)   /* call order violated (append after finish, ...)       */
+
+/* Grid geometry fixed by the reference: main.c:30-32
+   (BBSIZE 0.05, NBB = 403 cells per axis of which 0..399 can be occupied,
+   linear key = i*NBB*NBB + j*NBB + k). */
+#define PC_NBB 403
+#define PC_NCELLS 65450827ull   /* 403^3 */
+#define PC_NLAYERS 400          /* occupied x layers */
+
+typedef struct pc_context pc_context;
+
+const char *pc_last_error(void);
+/* "major.minor" of this ABI and the gfx target the kernels were built for. */
+const char *pc_version(void);
+
+/* ---- streaming interface: the reference's seams ------------------------- */
+
+/* Replaces init_hashmap(hm, capacity) (hashmap.h:31,45; called at
+   main.c:316-317 with file_size/128).  `device` is the HIP device ordinal;
+   `expected_points` is a capacity hint (0 = unknown; storage grows on demand). */
+int pc_create(pc_context **ctx, int device, uint64_t expected_points);
+
+/* Restricts the context to one x-slab of a sharded run: only cells whose x
+   index is in [x_lo, x_hi) are home cells.  The caller appends the slab's
+   points plus those of layer x_hi (the +x halo: every neighbour offset at
+   main.c:195-209 has di in {0,+1}).  Default is the whole grid, [0, 400).
+   No counterpart in the reference (single process). */
+int pc_set_slab(pc_context *ctx, int x_lo, int x_hi);
+
+/* Replaces the per-point sink insert(hm, key, val) (hashmap.h:33,94; called
+   from every parser thread at main.c:137).  Appends n points given as packed
+   float x,y,z triples in HOST memory.  Thread-safe: parser threads call it
+   concurrently, each with its own buffer; the data is copied before return.
+   The cell key (main.c:134-136) is computed by the library on the GPU. */
+int pc_append(pc_context *ctx, const float *xyz, uint64_t n);
+
+/* Same, for points that already live in device memory (copied device to
+   device on `stream`, which must be complete before pc_finish). */
+int pc_append_device(pc_context *ctx, const float *d_xyz, uint64_t n, void *stream);
+
+/* Replaces flatten(hm,&keys,&size) + count(hm,keys,len) (hashmap.h:34,137;
+   main.c:236,331-335): bins every appended point and counts the pairs.
+   Called once, from one thread, after all appends returned.  *npairs is the
+   value the reference prints with "%ld\n" (main.c:336).  Blocks until done. */
+int pc_finish(pc_context *ctx, int64_t *npairs);
+
+/* Number of dist2() evaluations the reference would make on the appended
+   points (sum over home cells of n(n-1)/2 + n*sum of 13 neighbour counts,
+   main.c:210-229); valid after pc_finish.  The unit of "pairs-tested/s". */
+int pc_tests(pc_context *ctx, int64_t *ntests);
+
+/* Points appended so far. */
+int pc_size(pc_context *ctx, uint64_t *n);
+
+/* Millisecond device timings of the last pc_finish: [0] binning, [1] count. */
+int pc_phase_ms(pc_context *ctx, float ms[2]);
+
+/* The reference never frees its table (process exit); a library must. */
+void pc_destroy(pc_context *ctx);
+
+/* ---- stateless device-pointer stages (no allocation, no host sync) ------- */
+/* These launch on `stream` and return immediately; all pointers are device
+   memory.  They are what the streaming interface runs internally and what the
+   parity tests and the benchmark drive directly. */
+
+/* Bytes of scratch pc_bin_device / pc_count_pairs_device need for n points. */
+size_t pc_workspace_bytes(uint64_t n);
+
+/* Cell keys, main.c:134-137: keys[p] = INDEX(cell(x), cell(y), cell(z)) with
+   cell(f) = (int)(((double)f + 10.0) / 0.05).  d_status (one int32, caller
+   zeroes it) gets bit 0 set if any point falls outside cells [0,400). */
+int pc_cell_keys_device(const float *d_xyz, uint64_t n, uint32_t *d_keys,
+                        int32_t *d_status, void *stream);
+
+/* Binning, replaces insert/atomic_insert/flatten (hashmap.h:69-153): writes
+   the points grouped by ascending key to d_sorted_xyz (3n floats) and the
+   table d_cell_start (PC_NCELLS+2 uint32): points of key c occupy
+   [cell_start[c], cell_start[c+1]).  Order inside a cell is unspecified (as
+   in the reference, whose chunk lists fill in thread arrival order). */
+int pc_bin_device(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
+                  uint32_t *d_cell_start, void *d_workspace, size_t workspace_bytes,
+                  int32_t *d_status, void *stream);
+
+/* Pair test, replaces counter_thread/compare/count_chunk/dist2
+   (main.c:85-91,161-234): ADDS to *d_npairs (uint64, caller zeroes) the number
+   of pairs (a,b), a in a home cell with x index in [x_lo,x_hi), b later in the
+   same cell or anywhere in its 13 forward neighbour cells (main.c:195-209),
+   with (dx*dx+dy*dy)+dz*dz <= 0.0025f in unfused binary32. */
+int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t *d_cell_start,
+                           uint64_t n, int x_lo, int x_hi, uint64_t *d_npairs,
+                           void *stream);
+
+/* ADDS to *d_ntests the reference's dist2() call count for home layers
+   [x_lo,x_hi), from the cell table alone. */
+int pc_count_tests_device(const uint32_t *d_cell_start, int x_lo, int x_hi,
+                          uint64_t *d_ntests, void *stream);
+
+/* Whole hot path on device-resident input: keys, binning, pair test.
+   d_sorted_xyz / d_cell_start as above (outputs, kept for inspection);
+   *d_npairs is overwritten with the count. */
+int pc_count_pairs_device(const float *d_xyz, uint64_t n, int x_lo, int x_hi,
+                          float *d_sorted_xyz, uint32_t *d_cell_start,
+                          void *d_workspace, size_t workspace_bytes,
+                          uint64_t *d_npairs, int32_t *d_status, void *stream);
+
+/* Selects kernel variants (for A/B measurement and cross-checks); values are
+   documented next to the kernels.  name: "bin" | "count".  Returns PC_ERR_ARG
+   for an unknown name or value. */
+int pc_set_variant(const char *name, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAIRCOUNT_H */

@@ -1,0 +1,247 @@
+"""MI355X-native pair counting: Python mirror of the reference's seams.
+
+The reference (Remmarg0rPA/particle-simulation) is a C program; its hot path is
+reached through init_hashmap / insert / flatten / count (src/hashmap.h:31-34,
+src/main.c:236).  This package binds the C ABI of libpaircount.so
+(include/paircount.h), which replaces exactly those calls, and exposes
+
+    PairCounter      -- create / append / finish, the streaming seam
+    DeviceStages     -- the stateless device-pointer stages on torch tensors
+
+PyTorch is used only as the owner of device memory and streams.  There is no
+CPU fallback: importing works anywhere, but every compute call needs the HIP
+library and a GPU and raises PairCountError otherwise.
+
+The directory name contains a hyphen (it follows the reference repository's
+name); load it with `load_package()` from the repository root's conftest or via
+importlib, under the module name ``particle_simulation_amd``.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpaircount.so")
+
+PC_NBB = 403
+PC_NCELLS = PC_NBB ** 3
+PC_NLAYERS = 400
+TABLE_LEN = PC_NCELLS + 2
+
+ERR_NAMES = {0: "PC_OK", -1: "PC_ERR_ARG", -2: "PC_ERR_HIP", -3: "PC_ERR_DOMAIN", -4: "PC_ERR_NOMEM", -5: "PC_ERR_STATE"}
+
+# every symbol include/paircount.h declares: (name, restype, argtypes)
+_c = ctypes
+_vp, _u64, _i32, _sz = _c.c_void_p, _c.c_uint64, _c.c_int, _c.c_size_t
+ABI = [
+    ("pc_last_error", _c.c_char_p, []),
+    ("pc_version", _c.c_char_p, []),
+    ("pc_create", _i32, [_c.POINTER(_vp), _i32, _u64]),
+    ("pc_set_slab", _i32, [_vp, _i32, _i32]),
+    ("pc_append", _i32, [_vp, _vp, _u64]),
+    ("pc_append_device", _i32, [_vp, _vp, _u64, _vp]),
+    ("pc_finish", _i32, [_vp, _c.POINTER(_c.c_int64)]),
+    ("pc_tests", _i32, [_vp, _c.POINTER(_c.c_int64)]),
+    ("pc_size", _i32, [_vp, _c.POINTER(_u64)]),
+    ("pc_phase_ms", _i32, [_vp, _c.POINTER(_c.c_float)]),
+    ("pc_destroy", None, [_vp]),
+    ("pc_workspace_bytes", _sz, [_u64]),
+    ("pc_cell_keys_device", _i32, [_vp, _u64, _vp, _vp, _vp]),
+    ("pc_bin_device", _i32, [_vp, _u64, _vp, _vp, _vp, _sz, _vp, _vp]),
+    ("pc_count_sorted_device", _i32, [_vp, _vp, _u64, _i32, _i32, _vp, _vp]),
+    ("pc_count_tests_device", _i32, [_vp, _i32, _i32, _vp, _vp]),
+    ("pc_count_pairs_device", _i32, [_vp, _u64, _i32, _i32, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    ("pc_set_variant", _i32, [_c.c_char_p, _i32]),
+]
+
+
+class PairCountError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("%s: %s" % (ERR_NAMES.get(code, str(code)), message))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """The loaded libpaircount.so.  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PairCountError(-2, "HIP library %s is missing; run __graft_entry__.build()" % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, restype, argtypes in ABI:
+            fn = getattr(handle, name)      # AttributeError if a declared symbol is not exported
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise PairCountError(rc, lib().pc_last_error().decode())
+
+
+def set_variant(name, value):
+    _check(lib().pc_set_variant(name.encode(), int(value)))
+
+
+def _host_ptr(arr):
+    import numpy as np
+    a = np.ascontiguousarray(arr, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] != 3:
+        a = a.reshape(-1, 3)
+    return a, a.ctypes.data_as(ctypes.c_void_p), a.shape[0]
+
+
+class PairCounter:
+    """Streaming seam: the object a host program holds instead of a Hashmap.
+
+    pc = PairCounter(device=0, expected_points=n)   # init_hashmap   (main.c:316-317)
+    pc.append(xyz_block)                            # insert, bulk   (main.c:137); thread-safe
+    npairs = pc.finish()                            # flatten+count  (main.c:331-335)
+    """
+
+    def __init__(self, device=0, expected_points=0, slab=None):
+        self._h = ctypes.c_void_p()
+        _check(lib().pc_create(ctypes.byref(self._h), int(device), int(expected_points)))
+        if slab is not None:
+            _check(lib().pc_set_slab(self._h, int(slab[0]), int(slab[1])))
+
+    def append(self, xyz):
+        a, p, n = _host_ptr(xyz)
+        _check(lib().pc_append(self._h, p, n))
+
+    def append_device(self, t):
+        import torch
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        n = t.numel() // 3
+        _check(lib().pc_append_device(self._h, t.data_ptr(), n, torch.cuda.current_stream(t.device).cuda_stream))
+
+    def size(self):
+        n = ctypes.c_uint64()
+        _check(lib().pc_size(self._h, ctypes.byref(n)))
+        return n.value
+
+    def finish(self):
+        r = ctypes.c_int64()
+        _check(lib().pc_finish(self._h, ctypes.byref(r)))
+        return r.value
+
+    def tests(self):
+        r = ctypes.c_int64()
+        _check(lib().pc_tests(self._h, ctypes.byref(r)))
+        return r.value
+
+    def phase_ms(self):
+        ms = (ctypes.c_float * 2)()
+        _check(lib().pc_phase_ms(self._h, ms))
+        return {"binning": ms[0], "count": ms[1]}
+
+    def close(self):
+        if self._h:
+            lib().pc_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceStages:
+    """The stateless stages on torch CUDA tensors (torch owns memory + stream).
+
+    Buffers are allocated once for `capacity` points and reused; no call here
+    synchronises or allocates, so the sequence can be timed with events on the
+    current torch stream.
+    """
+
+    def __init__(self, capacity, device="cuda:0"):
+        import torch
+        self.torch = torch
+        self.device = torch.device(device)
+        self.capacity = int(capacity)
+        n = max(self.capacity, 1)
+        self.ws_bytes = lib().pc_workspace_bytes(n)
+        with torch.cuda.device(self.device):
+            self.sorted = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+            self.table = torch.empty(TABLE_LEN, dtype=torch.int32, device=self.device)
+            self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device)
+            self.result = torch.zeros(2, dtype=torch.int64, device=self.device)   # [pairs, tests]
+            self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def _n(self, xyz):
+        t = self.torch
+        assert xyz.is_cuda and xyz.dtype == t.float32 and xyz.is_contiguous(), "xyz must be a contiguous float32 CUDA tensor"
+        n = xyz.numel() // 3
+        if n > self.capacity:
+            raise PairCountError(-1, "n=%d exceeds DeviceStages capacity %d" % (n, self.capacity))
+        return n
+
+    def cell_keys(self, xyz, keys=None):
+        n = self._n(xyz)
+        if keys is None:
+            keys = self.torch.empty(max(n, 1), dtype=self.torch.int32, device=self.device)
+        _check(lib().pc_cell_keys_device(xyz.data_ptr(), n, keys.data_ptr(), self.status.data_ptr(), self._stream()))
+        return keys[:n]
+
+    def bin(self, xyz):
+        n = self._n(xyz)
+        _check(lib().pc_bin_device(xyz.data_ptr(), n, self.sorted.data_ptr(), self.table.data_ptr(),
+                                   self.ws.data_ptr(), self.ws_bytes, self.status.data_ptr(), self._stream()))
+        return n
+
+    def count_sorted(self, n, x_lo=0, x_hi=PC_NLAYERS, zero=True):
+        if zero:
+            self.result[0:1].zero_()
+        _check(lib().pc_count_sorted_device(self.sorted.data_ptr(), self.table.data_ptr(), n, x_lo, x_hi,
+                                            self.result.data_ptr(), self._stream()))
+
+    def count_tests(self, x_lo=0, x_hi=PC_NLAYERS, zero=True):
+        if zero:
+            self.result[1:2].zero_()
+        _check(lib().pc_count_tests_device(self.table.data_ptr(), x_lo, x_hi,
+                                           self.result.data_ptr() + 8, self._stream()))
+
+    def count_pairs(self, xyz, x_lo=0, x_hi=PC_NLAYERS):
+        """Whole hot path, asynchronous; the count lands in self.result[0]."""
+        n = self._n(xyz)
+        _check(lib().pc_count_pairs_device(xyz.data_ptr(), n, x_lo, x_hi, self.sorted.data_ptr(),
+                                           self.table.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
+                                           self.result.data_ptr(), self.status.data_ptr(), self._stream()))
+        return n
+
+    def pairs(self):
+        """Synchronises and returns the last count; raises on a domain error."""
+        st = int(self.status.item())
+        if st & 1:
+            self.status.zero_()
+            raise PairCountError(-3, "a coordinate lies outside the reference's domain (-10,10)")
+        return int(self.result[0].item())
+
+    def tests(self):
+        return int(self.result[1].item())
+
+
+def count_pairs(xyz, device="cuda:0", x_lo=0, x_hi=PC_NLAYERS):
+    """Convenience: count pairs among host or device points on one GPU."""
+    import torch
+    if not isinstance(xyz, torch.Tensor):
+        a, _, _ = _host_ptr(xyz)
+        xyz = torch.from_numpy(a)
+    xyz = xyz.to(device=device, dtype=torch.float32).contiguous().reshape(-1, 3)
+    st = DeviceStages(xyz.shape[0], device)
+    st.count_pairs(xyz, x_lo, x_hi)
+    return st.pairs()

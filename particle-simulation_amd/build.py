@@ -1,0 +1,103 @@
+"""Build driver: compiles the HIP library and the C host tools in-tree.
+
+    python particle-simulation_amd/build.py [--force]
+
+Outputs (all git-ignored, all shipped to the GPU box with the tree):
+    particle-simulation_amd/libpaircount.so   HIP kernels + C ABI (include/paircount.h)
+    particle-simulation_amd/libxyzhost.so     host tokenizer + synthetic-input generator
+    particle-simulation_amd/main              C host program, the reference's CLI
+After compiling, the device ISA is scanned: any fused binary32 multiply-add in
+the pair-test or key kernels would change results, so the build fails on one.
+"""
+import os
+import re
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "host")
+ARCH = "gfx950"
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CC = os.environ.get("CC", "gcc")
+
+HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall"]
+C_FLAGS = ["-O2", "-std=c11", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-pthread", "-Wall", "-Wextra"]
+
+FUSED_F32 = re.compile(r"\bv_(pk_)?(fma|fmac|mad|mac|fma_mix|fmamk|fmaak)_f32\b")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build step failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def _sources(d, exts):
+    return [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith(exts)]
+
+
+def build_hip(force=False):
+    out = os.path.join(HERE, "libpaircount.so")
+    srcs = _sources(CSRC, (".hip", ".h")) + [os.path.join(ROOT, "include", "paircount.h")]
+    if not (force or _newer(out, srcs)):
+        return out
+    main_src = os.path.join(CSRC, "paircount.hip")
+    asm = os.path.join(HERE, "build", "paircount_gfx950.s")
+    os.makedirs(os.path.dirname(asm), exist_ok=True)
+    _run([HIPCC] + HIP_FLAGS + ["-S", "--cuda-device-only", "-Wno-unused-command-line-argument", "-o", asm, main_src])
+    with open(asm) as f:
+        bad = [ln.strip() for ln in f if FUSED_F32.search(ln)]
+    if bad:
+        raise RuntimeError("fused f32 multiply-add in device code (breaks bit-exact parity):\n" + "\n".join(bad[:10]))
+    _run([HIPCC] + HIP_FLAGS + ["-shared", "-o", out, main_src, "-lpthread"])
+    return out
+
+
+def build_host(force=False):
+    outs = []
+    if not os.path.isdir(HOST):
+        return outs
+    hdrs = _sources(HOST, (".h",)) + [os.path.join(ROOT, "include", "paircount.h")]
+    gen = os.path.join(HOST, "xyzhost.c")
+    if os.path.exists(gen):
+        out = os.path.join(HERE, "libxyzhost.so")
+        if force or _newer(out, [gen] + hdrs):
+            _run([CC] + C_FLAGS + ["-shared", "-o", out, gen])
+        outs.append(out)
+    main_c = os.path.join(HOST, "main.c")
+    if os.path.exists(main_c):
+        out = os.path.join(HERE, "main")
+        if force or _newer(out, [main_c] + hdrs + [os.path.join(HERE, "libpaircount.so")]):
+            _run([CC] + C_FLAGS + ["-o", out, main_c, "-L" + HERE, "-lpaircount", "-Wl,-rpath,$ORIGIN"])
+        outs.append(out)
+    return outs
+
+
+def build_oracle(force=False):
+    """The CPU checker (test infrastructure).  Building it is not using it."""
+    odir = os.path.join(ROOT, "oracle")
+    _run(["make", "-C", odir] + (["-B"] if force else []))
+    return os.path.join(odir, "liboracle.so")
+
+
+def build_all(force=False):
+    lib = build_hip(force)
+    host = build_host(force)
+    orc = build_oracle(force)
+    return [lib] + host + [orc]
+
+
+if __name__ == "__main__":
+    for p in build_all("--force" in sys.argv):
+        print("built", os.path.relpath(p, ROOT))

@@ -1,0 +1,402 @@
+// libpaircount.so -- C ABI (include/paircount.h) over the HIP kernels.
+// One translation unit; gfx950 only.
+#include "../../include/paircount.h"
+
+#include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pc_bin_atomic.h"
+#include "pc_count_global.h"
+
+// ------------------------------------------------------------------ errors --
+static thread_local char g_err[512] = "";
+
+static int pc_fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define PC_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return pc_fail(PC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                           __FILE__, __LINE__);                                              \
+    } while (0)
+
+extern "C" const char *pc_last_error(void) { return g_err; }
+extern "C" const char *pc_version(void) { return "1.0 gfx950"; }
+
+// ---------------------------------------------------------------- variants --
+static int g_variant_bin = 0;     // 0 = atomic counting sort
+static int g_variant_count = 0;   // 0 = global-memory pair test
+
+extern "C" int pc_set_variant(const char *name, int value)
+{
+    if (!name) return pc_fail(PC_ERR_ARG, "pc_set_variant: null name");
+    if (!strcmp(name, "bin")) {
+        if (value != 0) return pc_fail(PC_ERR_ARG, "pc_set_variant: bin variant %d unknown", value);
+        g_variant_bin = value;
+        return PC_OK;
+    }
+    if (!strcmp(name, "count")) {
+        if (value != 0) return pc_fail(PC_ERR_ARG, "pc_set_variant: count variant %d unknown", value);
+        g_variant_count = value;
+        return PC_OK;
+    }
+    return pc_fail(PC_ERR_ARG, "pc_set_variant: unknown name '%s'", name);
+}
+
+// ------------------------------------------------------------------ stages --
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static const uint64_t PC_MAX_POINTS = 0xFFFFFFF0ull;   // slots are uint32
+
+static inline uint32_t scan_tiles(uint64_t m) { return (uint32_t)((m + PC_SCAN_TILE - 1) / PC_SCAN_TILE); }
+
+extern "C" size_t pc_workspace_bytes(uint64_t n)
+{
+    size_t keys = align_up((size_t)n * 4 + 4, 256);
+    size_t sums = align_up((size_t)scan_tiles(PC_NCELLS + 2) * 4, 256);
+    return keys + sums + 256;
+}
+
+static inline int grid_for(uint64_t n, int tpb, int cap)
+{
+    uint64_t g = (n + tpb - 1) / tpb;
+    if (g < 1) g = 1;
+    if (g > (uint64_t)cap) g = cap;
+    return (int)g;
+}
+
+extern "C" int pc_cell_keys_device(const float *d_xyz, uint64_t n, uint32_t *d_keys,
+                                   int32_t *d_status, void *stream)
+{
+    if ((!d_xyz || !d_keys) && n) return pc_fail(PC_ERR_ARG, "pc_cell_keys_device: null pointer");
+    if (!d_status) return pc_fail(PC_ERR_ARG, "pc_cell_keys_device: null status");
+    if (n > PC_MAX_POINTS) return pc_fail(PC_ERR_ARG, "pc_cell_keys_device: n too large");
+    if (n == 0) return PC_OK;
+    hipLaunchKernelGGL(pc_keys_only, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       d_xyz, n, d_keys, d_status);
+    PC_HIP(hipGetLastError());
+    return PC_OK;
+}
+
+extern "C" int pc_bin_device(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
+                             uint32_t *d_cell_start, void *d_workspace, size_t workspace_bytes,
+                             int32_t *d_status, void *stream)
+{
+    if (!d_cell_start || !d_status || !d_workspace)
+        return pc_fail(PC_ERR_ARG, "pc_bin_device: null pointer");
+    if ((!d_xyz || !d_sorted_xyz) && n) return pc_fail(PC_ERR_ARG, "pc_bin_device: null point array");
+    if (n > PC_MAX_POINTS) return pc_fail(PC_ERR_ARG, "pc_bin_device: n too large");
+    if (workspace_bytes < pc_workspace_bytes(n))
+        return pc_fail(PC_ERR_ARG, "pc_bin_device: workspace %zu < %zu bytes", workspace_bytes,
+                       pc_workspace_bytes(n));
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t m = PC_NCELLS + 2;
+    uint32_t *keys = (uint32_t *)d_workspace;
+    uint32_t *sums = (uint32_t *)((char *)d_workspace + align_up((size_t)n * 4 + 4, 256));
+    const uint32_t ntiles = scan_tiles(m);
+
+    PC_HIP(hipMemsetAsync(d_cell_start, 0, m * sizeof(uint32_t), s));
+    if (n)
+        hipLaunchKernelGGL(pc_a1_keys_hist, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, d_xyz, n, keys,
+                           d_cell_start, d_status);
+    hipLaunchKernelGGL(pc_a2_scan_reduce, dim3(ntiles), dim3(PC_SCAN_TPB), 0, s, d_cell_start, m, sums);
+    hipLaunchKernelGGL(pc_a2_scan_spine, dim3(1), dim3(PC_SCAN_TPB), 0, s, sums, ntiles);
+    hipLaunchKernelGGL(pc_a2_scan_apply, dim3(ntiles), dim3(PC_SCAN_TPB), 0, s, d_cell_start, m, sums);
+    if (n)
+        hipLaunchKernelGGL(pc_a3_scatter, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, d_xyz, keys, n,
+                           d_cell_start, d_sorted_xyz);
+    PC_HIP(hipGetLastError());
+    return PC_OK;
+}
+
+static int check_slab(const char *who, int x_lo, int x_hi)
+{
+    if (x_lo < 0 || x_hi > PC_NLAYERS || x_lo > x_hi)
+        return pc_fail(PC_ERR_ARG, "%s: slab [%d,%d) not within [0,%d]", who, x_lo, x_hi, PC_NLAYERS);
+    return PC_OK;
+}
+
+extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t *d_cell_start,
+                                      uint64_t n, int x_lo, int x_hi, uint64_t *d_npairs,
+                                      void *stream)
+{
+    if (!d_cell_start || !d_npairs) return pc_fail(PC_ERR_ARG, "pc_count_sorted_device: null pointer");
+    if (!d_sorted_xyz && n) return pc_fail(PC_ERR_ARG, "pc_count_sorted_device: null point array");
+    if (n > PC_MAX_POINTS) return pc_fail(PC_ERR_ARG, "pc_count_sorted_device: n too large");
+    int rc = check_slab("pc_count_sorted_device", x_lo, x_hi);
+    if (rc) return rc;
+    if (n == 0 || x_lo == x_hi) return PC_OK;
+    uint32_t c_lo = (uint32_t)x_lo * PC_NBB2, c_hi = (uint32_t)x_hi * PC_NBB2;
+    hipLaunchKernelGGL(pc_c0_count_global, dim3(grid_for(n, 256, 1 << 20)), dim3(256), 0,
+                       (hipStream_t)stream, d_sorted_xyz, d_cell_start, c_lo, c_hi,
+                       (unsigned long long *)d_npairs);
+    PC_HIP(hipGetLastError());
+    return PC_OK;
+}
+
+extern "C" int pc_count_tests_device(const uint32_t *d_cell_start, int x_lo, int x_hi,
+                                     uint64_t *d_ntests, void *stream)
+{
+    if (!d_cell_start || !d_ntests) return pc_fail(PC_ERR_ARG, "pc_count_tests_device: null pointer");
+    int rc = check_slab("pc_count_tests_device", x_lo, x_hi);
+    if (rc) return rc;
+    if (x_lo == x_hi) return PC_OK;
+    uint32_t c_lo = (uint32_t)x_lo * PC_NBB2, c_hi = (uint32_t)x_hi * PC_NBB2;
+    hipLaunchKernelGGL(pc_count_tests, dim3(8192), dim3(256), 0, (hipStream_t)stream, d_cell_start, c_lo,
+                       c_hi, (unsigned long long *)d_ntests);
+    PC_HIP(hipGetLastError());
+    return PC_OK;
+}
+
+extern "C" int pc_count_pairs_device(const float *d_xyz, uint64_t n, int x_lo, int x_hi,
+                                     float *d_sorted_xyz, uint32_t *d_cell_start,
+                                     void *d_workspace, size_t workspace_bytes,
+                                     uint64_t *d_npairs, int32_t *d_status, void *stream)
+{
+    if (!d_npairs) return pc_fail(PC_ERR_ARG, "pc_count_pairs_device: null result pointer");
+    int rc = check_slab("pc_count_pairs_device", x_lo, x_hi);
+    if (rc) return rc;
+    rc = pc_bin_device(d_xyz, n, d_sorted_xyz, d_cell_start, d_workspace, workspace_bytes, d_status, stream);
+    if (rc) return rc;
+    PC_HIP(hipMemsetAsync(d_npairs, 0, sizeof(uint64_t), (hipStream_t)stream));
+    return pc_count_sorted_device(d_sorted_xyz, d_cell_start, n, x_lo, x_hi, d_npairs, stream);
+}
+
+// --------------------------------------------------------------- streaming --
+struct pc_context {
+    int device;
+    int x_lo, x_hi;
+    pthread_rwlock_t lock;      // appends: read side while copying; growth: write side
+    pthread_mutex_t reserve;    // serialises slot reservation
+    float *d_xyz;
+    uint64_t cap, size;
+    int finished;
+    int64_t npairs, ntests;
+    float ms[2];
+};
+
+extern "C" int pc_create(pc_context **out, int device, uint64_t expected_points)
+{
+    if (!out) return pc_fail(PC_ERR_ARG, "pc_create: null out pointer");
+    *out = NULL;
+    int ndev = 0;
+    PC_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+        return pc_fail(PC_ERR_ARG, "pc_create: device %d not in [0,%d)", device, ndev);
+    if (expected_points > PC_MAX_POINTS) return pc_fail(PC_ERR_ARG, "pc_create: expected_points too large");
+    PC_HIP(hipSetDevice(device));
+    pc_context *c = (pc_context *)calloc(1, sizeof *c);
+    if (!c) return pc_fail(PC_ERR_NOMEM, "pc_create: out of host memory");
+    c->device = device;
+    c->x_lo = 0;
+    c->x_hi = PC_NLAYERS;
+    c->cap = expected_points ? expected_points : (1u << 20);
+    pthread_rwlock_init(&c->lock, NULL);
+    pthread_mutex_init(&c->reserve, NULL);
+    hipError_t e = hipMalloc((void **)&c->d_xyz, c->cap * 12);
+    if (e != hipSuccess) {
+        free(c);
+        return pc_fail(PC_ERR_NOMEM, "pc_create: hipMalloc(%llu points): %s", (unsigned long long)c->cap,
+                       hipGetErrorString(e));
+    }
+    *out = c;
+    return PC_OK;
+}
+
+extern "C" int pc_set_slab(pc_context *c, int x_lo, int x_hi)
+{
+    if (!c) return pc_fail(PC_ERR_ARG, "pc_set_slab: null context");
+    int rc = check_slab("pc_set_slab", x_lo, x_hi);
+    if (rc) return rc;
+    c->x_lo = x_lo;
+    c->x_hi = x_hi;
+    return PC_OK;
+}
+
+// Reserve [off, off+n) in the device array, growing it if needed; returns with
+// the read lock held so the array cannot move while the caller copies.
+static int reserve_slots(pc_context *c, uint64_t n, uint64_t *off)
+{
+    for (;;) {
+        pthread_rwlock_rdlock(&c->lock);
+        pthread_mutex_lock(&c->reserve);
+        if (c->finished) {
+            pthread_mutex_unlock(&c->reserve);
+            pthread_rwlock_unlock(&c->lock);
+            return pc_fail(PC_ERR_STATE, "append after pc_finish");
+        }
+        if (c->size + n <= c->cap) {
+            *off = c->size;
+            c->size += n;
+            pthread_mutex_unlock(&c->reserve);
+            return PC_OK;                       // read lock stays held
+        }
+        uint64_t need = c->size + n;
+        pthread_mutex_unlock(&c->reserve);
+        pthread_rwlock_unlock(&c->lock);
+        if (need > PC_MAX_POINTS) return pc_fail(PC_ERR_ARG, "more than %llu points", (unsigned long long)PC_MAX_POINTS);
+
+        pthread_rwlock_wrlock(&c->lock);        // no copy in flight now
+        if (need > c->cap) {
+            uint64_t ncap = c->cap * 2 > need ? c->cap * 2 : need;
+            if (ncap > PC_MAX_POINTS) ncap = PC_MAX_POINTS;
+            float *nd = NULL;
+            hipError_t e = hipMalloc((void **)&nd, ncap * 12);
+            if (e == hipSuccess && c->size)
+                e = hipMemcpy(nd, c->d_xyz, c->size * 12, hipMemcpyDeviceToDevice);
+            if (e != hipSuccess) {
+                if (nd) (void)hipFree(nd);
+                pthread_rwlock_unlock(&c->lock);
+                return pc_fail(PC_ERR_NOMEM, "growing the point array to %llu: %s", (unsigned long long)ncap,
+                               hipGetErrorString(e));
+            }
+            (void)hipFree(c->d_xyz);
+            c->d_xyz = nd;
+            c->cap = ncap;
+        }
+        pthread_rwlock_unlock(&c->lock);
+    }
+}
+
+extern "C" int pc_append(pc_context *c, const float *xyz, uint64_t n)
+{
+    if (!c) return pc_fail(PC_ERR_ARG, "pc_append: null context");
+    if (n == 0) return PC_OK;
+    if (!xyz) return pc_fail(PC_ERR_ARG, "pc_append: null points");
+    PC_HIP(hipSetDevice(c->device));            // the device is per-thread state
+    uint64_t off;
+    int rc = reserve_slots(c, n, &off);
+    if (rc) return rc;
+    hipError_t e = hipMemcpy(c->d_xyz + 3 * off, xyz, n * 12, hipMemcpyHostToDevice);
+    pthread_rwlock_unlock(&c->lock);
+    if (e != hipSuccess) return pc_fail(PC_ERR_HIP, "pc_append: hipMemcpy: %s", hipGetErrorString(e));
+    return PC_OK;
+}
+
+extern "C" int pc_append_device(pc_context *c, const float *d_xyz, uint64_t n, void *stream)
+{
+    if (!c) return pc_fail(PC_ERR_ARG, "pc_append_device: null context");
+    if (n == 0) return PC_OK;
+    if (!d_xyz) return pc_fail(PC_ERR_ARG, "pc_append_device: null points");
+    PC_HIP(hipSetDevice(c->device));
+    uint64_t off;
+    int rc = reserve_slots(c, n, &off);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(c->d_xyz + 3 * off, d_xyz, n * 12, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    pthread_rwlock_unlock(&c->lock);
+    if (e != hipSuccess) return pc_fail(PC_ERR_HIP, "pc_append_device: copy: %s", hipGetErrorString(e));
+    return PC_OK;
+}
+
+extern "C" int pc_size(pc_context *c, uint64_t *n)
+{
+    if (!c || !n) return pc_fail(PC_ERR_ARG, "pc_size: null pointer");
+    pthread_mutex_lock(&c->reserve);
+    *n = c->size;
+    pthread_mutex_unlock(&c->reserve);
+    return PC_OK;
+}
+
+struct finish_bufs {
+    float *sorted = nullptr;
+    uint32_t *table = nullptr;
+    void *ws = nullptr;
+    uint64_t *res = nullptr;     // [0] pairs, [1] tests
+    int32_t *status = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    ~finish_bufs()
+    {
+        if (sorted) (void)hipFree(sorted);
+        if (table) (void)hipFree(table);
+        if (ws) (void)hipFree(ws);
+        if (res) (void)hipFree(res);
+        if (status) (void)hipFree(status);
+        for (auto e : ev) if (e) (void)hipEventDestroy(e);
+    }
+};
+
+extern "C" int pc_finish(pc_context *c, int64_t *npairs)
+{
+    if (!c || !npairs) return pc_fail(PC_ERR_ARG, "pc_finish: null pointer");
+    pthread_rwlock_wrlock(&c->lock);
+    if (c->finished) {
+        pthread_rwlock_unlock(&c->lock);
+        *npairs = c->npairs;
+        return PC_OK;
+    }
+    c->finished = 1;
+    pthread_rwlock_unlock(&c->lock);
+    PC_HIP(hipSetDevice(c->device));
+    const uint64_t n = c->size;
+    finish_bufs b;
+    const size_t wsb = pc_workspace_bytes(n);
+    if (hipMalloc((void **)&b.sorted, (n ? n : 1) * 12) != hipSuccess ||
+        hipMalloc((void **)&b.table, (PC_NCELLS + 2) * 4) != hipSuccess ||
+        hipMalloc(&b.ws, wsb) != hipSuccess || hipMalloc((void **)&b.res, 16) != hipSuccess ||
+        hipMalloc((void **)&b.status, 4) != hipSuccess)
+        return pc_fail(PC_ERR_NOMEM, "pc_finish: device allocation failed for %llu points", (unsigned long long)n);
+    for (auto &e : b.ev) PC_HIP(hipEventCreate(&e));
+    hipStream_t s = nullptr;
+    PC_HIP(hipMemsetAsync(b.res, 0, 16, s));
+    PC_HIP(hipMemsetAsync(b.status, 0, 4, s));
+    PC_HIP(hipEventRecord(b.ev[0], s));
+    int rc = pc_bin_device(c->d_xyz, n, b.sorted, b.table, b.ws, wsb, b.status, s);
+    if (rc) return rc;
+    PC_HIP(hipEventRecord(b.ev[1], s));
+    rc = pc_count_sorted_device(b.sorted, b.table, n, c->x_lo, c->x_hi, b.res, s);
+    if (rc) return rc;
+    PC_HIP(hipEventRecord(b.ev[2], s));
+    rc = pc_count_tests_device(b.table, c->x_lo, c->x_hi, b.res + 1, s);
+    if (rc) return rc;
+    uint64_t host_res[2];
+    int32_t host_status = 0;
+    PC_HIP(hipMemcpyAsync(host_res, b.res, 16, hipMemcpyDeviceToHost, s));
+    PC_HIP(hipMemcpyAsync(&host_status, b.status, 4, hipMemcpyDeviceToHost, s));
+    PC_HIP(hipStreamSynchronize(s));
+    PC_HIP(hipEventElapsedTime(&c->ms[0], b.ev[0], b.ev[1]));
+    PC_HIP(hipEventElapsedTime(&c->ms[1], b.ev[1], b.ev[2]));
+    if (host_status & 1)
+        return pc_fail(PC_ERR_DOMAIN, "a coordinate lies outside the reference's domain (-10,10)");
+    c->npairs = (int64_t)host_res[0];
+    c->ntests = (int64_t)host_res[1];
+    *npairs = c->npairs;
+    return PC_OK;
+}
+
+extern "C" int pc_tests(pc_context *c, int64_t *ntests)
+{
+    if (!c || !ntests) return pc_fail(PC_ERR_ARG, "pc_tests: null pointer");
+    if (!c->finished) return pc_fail(PC_ERR_STATE, "pc_tests before pc_finish");
+    *ntests = c->ntests;
+    return PC_OK;
+}
+
+extern "C" int pc_phase_ms(pc_context *c, float ms[2])
+{
+    if (!c || !ms) return pc_fail(PC_ERR_ARG, "pc_phase_ms: null pointer");
+    if (!c->finished) return pc_fail(PC_ERR_STATE, "pc_phase_ms before pc_finish");
+    ms[0] = c->ms[0];
+    ms[1] = c->ms[1];
+    return PC_OK;
+}
+
+extern "C" void pc_destroy(pc_context *c)
+{
+    if (!c) return;
+    if (hipSetDevice(c->device) == hipSuccess && c->d_xyz) (void)hipFree(c->d_xyz);
+    pthread_rwlock_destroy(&c->lock);
+    pthread_mutex_destroy(&c->reserve);
+    free(c);
+}

@@ -1,0 +1,64 @@
+// Pair test, variant 0 ("global"): one thread per home particle, candidates
+// read straight from global memory.  Restates counter_thread's loop nest
+// (reference main.c:210-229) literally on the sorted array: the 13 forward
+// neighbour cells of key c are the five contiguous key ranges
+//   c+1 | c+402..c+404 | c+162005..c+162007 | c+162408..c+162410 | c+162811..c+162813
+// (offsets of main.c:195-209; the 403-wide padding keeps face aliasing empty),
+// and "later points of the same cell" are the sorted slots after the home
+// particle.  Efficient only when a wave's lanes share candidates (dense cells);
+// the cross-check for the LDS-tiled variant.  pc_set_variant("count", 0).
+#pragma once
+#include "pc_device.h"
+
+__global__ void __launch_bounds__(256)
+pc_c0_count_global(const float *__restrict__ pts, const uint32_t *__restrict__ T,
+                   uint32_t c_lo, uint32_t c_hi,   // home keys [c_lo, c_hi)
+                   unsigned long long *__restrict__ out)
+{
+    unsigned long long acc = 0;
+    const uint32_t first = T[c_lo], last = T[c_hi];   // their slots in sorted order
+    uint32_t stride = gridDim.x * blockDim.x;
+    for (uint64_t p64 = (uint64_t)first + blockIdx.x * blockDim.x + threadIdx.x; p64 < last; p64 += stride) {
+        uint32_t p = (uint32_t)p64;
+        float x = pts[3 * (uint64_t)p], y = pts[3 * (uint64_t)p + 1], z = pts[3 * (uint64_t)p + 2];
+        uint32_t c = pc_key(pc_cell_index(x), pc_cell_index(y), pc_cell_index(z));
+        uint32_t cnt = 0;
+        // same cell (later slots) and cell c+1: slots (p, T[c+2])
+        uint32_t lo = p + 1, hi = T[c + 2];
+        for (uint32_t q = lo; q < hi; q++)
+            cnt += pc_hit(x, y, z, pts[3 * (uint64_t)q], pts[3 * (uint64_t)q + 1], pts[3 * (uint64_t)q + 2]);
+        const uint32_t base[4] = {402u, 162005u, 162408u, 162811u};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            lo = T[c + base[r]];
+            hi = T[c + base[r] + 3];
+            for (uint32_t q = lo; q < hi; q++)
+                cnt += pc_hit(x, y, z, pts[3 * (uint64_t)q], pts[3 * (uint64_t)q + 1], pts[3 * (uint64_t)q + 2]);
+        }
+        acc += cnt;
+    }
+    pc_block_add_u64<4>(acc, out);
+}
+
+// dist2() call count of the reference for home cells [c_first, c_last):
+//   sum_c  n_c(n_c-1)/2 + n_c * (points in the 13 forward neighbour cells)
+__global__ void __launch_bounds__(256)
+pc_count_tests(const uint32_t *__restrict__ T, uint32_t c_first, uint32_t c_last,
+               unsigned long long *__restrict__ out)
+{
+    unsigned long long acc = 0;
+    uint32_t stride = gridDim.x * blockDim.x;
+    for (uint64_t c64 = (uint64_t)c_first + blockIdx.x * blockDim.x + threadIdx.x; c64 < c_last; c64 += stride) {
+        uint32_t c = (uint32_t)c64;
+        uint32_t b = T[c], e = T[c + 1];
+        unsigned long long nc = e - b;
+        if (nc == 0) continue;
+        unsigned long long nb = (unsigned long long)(T[c + 2] - e)
+                              + (T[c + 405] - T[c + 402])
+                              + (T[c + 162008] - T[c + 162005])
+                              + (T[c + 162411] - T[c + 162408])
+                              + (T[c + 162814] - T[c + 162811]);
+        acc += nc * (nc - 1) / 2 + nc * nb;
+    }
+    pc_block_add_u64<4>(acc, out);
+}

@@ -1,0 +1,73 @@
+// Device-side arithmetic shared by every kernel of the pair-counting path.
+// gfx950 only (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/paircount.h"   // PC_NBB, PC_NCELLS, PC_NLAYERS
+#define PC_NBB2 (PC_NBB * PC_NBB)
+#define PC_WAVE 64
+
+// Cell index along one axis: reference main.c:134-136,
+//   (int)((f - (-10.)) / 0.05)   with f promoted to double.
+// f - (-10.0) and f + 10.0 are the same IEEE operation; the divide must stay a
+// correctly rounded binary64 division (no reciprocal multiply).
+__device__ __forceinline__ int pc_cell_index(float f)
+{
+    return (int)(((double)f + 10.0) / 0.05);
+}
+
+// Linear key: reference main.c:32 INDEX(i,j,k).
+__device__ __forceinline__ uint32_t pc_key(int i, int j, int k)
+{
+    return (uint32_t)(i * PC_NBB2 + j * PC_NBB + k);
+}
+
+__device__ __forceinline__ bool pc_in_grid(int i, int j, int k)
+{
+    return ((unsigned)i < 400u) & ((unsigned)j < 400u) & ((unsigned)k < 400u);
+}
+
+// Distance predicate: reference main.c:85-91 (dpps imm 0x71) and main.c:165.
+// Three products, summed as (dx*dx + dy*dy) + dz*dz, every step a separately
+// rounded binary32 operation -- __fmul_rn/__fadd_rn are never contracted into
+// an FMA.  (double)d2 <= 0.0025 is equivalent to d2 <= 0.0025f because
+// 0.0025f < 0.0025 < nextafterf(0.0025f, 1).
+__device__ __forceinline__ bool pc_hit(float xi, float yi, float zi, float xj, float yj, float zj)
+{
+    float dx = __fsub_rn(xi, xj), dy = __fsub_rn(yi, yj), dz = __fsub_rn(zi, zj);
+    float s = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    return s <= 0.0025f;
+}
+
+// Sum of a 32-bit value over the wave (DPP row ops + cross-row broadcast).
+__device__ __forceinline__ uint32_t pc_wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Block-wide sum of per-thread 64-bit partials, one atomic per block.
+// NWAVES = blockDim.x / 64.  Every thread of the block must call it.
+template <int NWAVES>
+__device__ __forceinline__ void pc_block_add_u64(unsigned long long part, unsigned long long *dst)
+{
+    __shared__ unsigned long long wsum[NWAVES];
+    unsigned long long s = part;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned l2 = __shfl_xor((unsigned)s, off, 64);
+        unsigned h2 = __shfl_xor((unsigned)(s >> 32), off, 64);
+        s += ((unsigned long long)h2 << 32) | l2;
+    }
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) wsum[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; w++) t += wsum[w];
+        if (t) atomicAdd(dst, t);
+    }
+}
