@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Benchmark of the pair-counting hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+One step = one pass of the hot path (cell keys, binning, pair test, and for
+N > 1 the 8-byte all-reduce) over synthetic points already resident in HBM.
+Workloads (BASELINE.json configs): uniform100m (default: the configuration the
+metric is quoted on), uniform10m, blobs100m, uniform1b (125 M points per GPU,
+weak scaling).  For N > 1 the x range is cut into N slabs, one rank per GPU;
+each rank holds its slab's points plus the +x halo layer.
+
+Prints ONE JSON line on rank 0.  value = reference dist2() evaluations covered
+per second by the whole job (tests of all ranks / max-over-ranks step time).
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak
+VALU_NOFMA_TOPS = 78.6           # fp32 vector peak without FMA credit (157.3 TFLOP/s / 2)
+
+WORKLOADS = {
+    # name: (kind, total points at N=1, sigma in micro-units, scaling, points multiply with ranks)
+    "uniform10m": ("uniform", 10_000_000, 0, "strong"),
+    "uniform100m": ("uniform", 100_000_000, 0, "strong"),
+    "blobs100m": ("blobs", 100_000_000, 500_000, "strong"),
+    "uniform1b": ("uniform", 125_000_000, 0, "weak"),
+}
+
+
+def kernel_bytes(name, n, layers):
+    """Algorithmic HBM bytes of one launch of each kernel, n points, `layers` x layers of cells."""
+    cells = (layers + 1) * 403 * 403
+    all_cells = 403 ** 3 + 2
+    table = {
+        "pc_a1_keys_hist": 12 * n + 4 * n + 8 * n,          # read xyz, write key, histogram read-modify-write
+        "pc_a2_scan_reduce": 4 * all_cells,
+        "pc_a2_scan_apply": 8 * all_cells,
+        "pc_a3_scatter": 4 * n + 12 * n + 8 * n + 12 * n,   # key, xyz in, cursor rmw, xyz out
+        "pc_c0_count_global": 12 * n + 4 * cells,
+        "pc_c1_count_tiles": 12 * n + 4 * cells,
+    }
+    return table.get(name)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="uniform100m", choices=sorted(WORKLOADS))
+    ap.add_argument("--points", type=int, default=0, help="override the workload's point count")
+    ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bin-variant", type=int, default=None)
+    ap.add_argument("--count-variant", type=int, default=None)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    psa = load_package()
+    import importlib
+    ht = importlib.import_module("particle_simulation_amd.hosttools")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    kind_name, base_points, sigma, scaling = WORKLOADS[args.workload]
+    total_points = args.points or (base_points * world if scaling == "weak" else base_points)
+    kind = ht.UNIFORM if kind_name == "uniform" else ht.BLOBS
+    cuts = ht.slab_cuts(world)
+    x_lo, x_hi = cuts[rank], cuts[rank + 1]
+    if args.bin_variant is not None:
+        psa.set_variant("bin", args.bin_variant)
+    if args.count_variant is not None:
+        psa.set_variant("count", args.count_variant)
+
+    # ---- synthetic input: this rank's slab plus its +x halo layer, resident in HBM ----
+    t_gen = time.time()
+    threads = max(1, ht.host_threads() // min(world, 8)) if world > 1 else ht.host_threads()
+    if world == 1:
+        host = ht.generate(kind, args.seed, total_points, sigma, threads=threads)
+    else:
+        host = ht.generate(kind, args.seed, total_points, sigma, x_lo=x_lo, x_hi=min(x_hi, 399), threads=threads)
+    n = host.shape[0]
+    xyz = torch.from_numpy(host).to(device)
+    del host
+    t_gen = time.time() - t_gen
+
+    st = psa.DeviceStages(n, device)
+    total = torch.zeros(1, dtype=torch.int64, device=device)
+
+    def step():
+        st.bin(xyz)
+        st.count_sorted(n, x_lo, x_hi)
+        if world > 1:
+            total.copy_(st.result[0:1])
+            dist.all_reduce(total)           # the path's only collective: one 8-byte sum
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    psa.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    psa.profile_enable(False)
+    prof = psa.profile_read()
+
+    pairs_local = st.pairs()
+    st.count_tests(x_lo, x_hi)
+    tests_local = st.tests()
+    agg = torch.tensor([pairs_local, tests_local, n], dtype=torch.int64, device=device)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(agg)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        assert int(total.item()) == int(agg[0].item()), "all-reduced count differs from the sum of rank counts"
+    pairs, tests, points_held = (int(v) for v in agg.tolist())
+    elapsed = float(tmax.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    if rank == 0:
+        # ---- per-kernel timings (HIP events on the launch stream, inside the timed region) ----
+        kernels = {}
+        for name, (timed, launches, ms) in prof.items():
+            if timed:
+                kernels[name] = {"avg_ms": ms / timed, "launches_per_step": launches / args.steps}
+        dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches_per_step"])
+        layers = x_hi - x_lo
+        for name, k in kernels.items():
+            b = kernel_bytes(name, n, layers)
+            if b:
+                k["algorithmic_gb"] = b / 1e9
+                k["achieved_gbs"] = b / 1e9 / (k["avg_ms"] * 1e-3)
+        bin_ms = sum(k["avg_ms"] * k["launches_per_step"] for nm, k in kernels.items() if not nm.startswith("pc_c"))
+        cnt_ms = sum(k["avg_ms"] * k["launches_per_step"] for nm, k in kernels.items() if nm.startswith("pc_c"))
+        dk = kernels[dom]
+        roofline = {
+            "kernel": dom, "bound": "hbm", "achieved": dk.get("achieved_gbs"), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": (dk.get("achieved_gbs") or 0.0) / HBM_PEAK_GBS, "traffic": None,
+            "avg_launch_ms": dk["avg_ms"],
+        }
+        binning_alg_gb = (44 * n + 8 * (layers + 1) * 403 * 403) / 1e9
+        out = {
+            "metric": "pairs-tested/s (reference dist2 evaluations covered per second, whole hot path: keys+binning+pair test)",
+            "value": tests / (elapsed / args.steps),
+            "unit": "pairs-tested/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "points": total_points, "points_held_incl_halo": points_held,
+                       "cutoff": 0.05, "slabs": world, "seed": args.seed,
+                       "generator_s": round(t_gen, 2)},
+            "pairs": pairs, "tests": tests,
+            "pairs_tested_per_s_pair_test_kernel_only": (tests_local / (cnt_ms * 1e-3)) if cnt_ms else None,
+            "binning_ms": bin_ms, "pair_test_ms": cnt_ms,
+            "binning_roofline": {"algorithmic_gb": binning_alg_gb,
+                                 "achieved_gbs": binning_alg_gb / (bin_ms * 1e-3) if bin_ms else None,
+                                 "frac_of_hbm_peak": binning_alg_gb / (bin_ms * 1e-3) / HBM_PEAK_GBS if bin_ms else None},
+            "pair_test_valu_frac": (9 * tests_local / (cnt_ms * 1e-3) / 1e12 / VALU_NOFMA_TOPS) if cnt_ms else None,
+            "kernels": kernels,
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(psa, ht, st, torch, kind, args.seed, total_points, sigma, device)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(psa, ht, st, torch, kind, seed, total_points, sigma, device):
+    """The reference binary (oracle/_ref, built from /root/reference in the build
+    container) on a bounded sample of the same workload: an x-slab of the stream
+    holding about 10 M points, same density.  Its count is compared with the HIP
+    count on the identical points.  Falls back to the C restatement (oracle/)
+    when the reference build is absent."""
+    import numpy as np
+    cores = ht.host_threads()
+    want = min(total_points, 10_000_000)
+    layers = max(1, min(400, round(400 * want / total_points)))
+    lo = 200 - layers // 2
+    hi = lo + layers - 1                       # inclusive cell range of the sample
+    tmp = tempfile.mkdtemp(prefix="pcbench_")
+    path = os.path.join(tmp, "sample.xyz")
+    try:
+        npts = ht.generate_text(path, kind, seed, total_points, sigma, x_lo=lo, x_hi=hi)
+        sample = ht.generate(kind, seed, total_points, sigma, x_lo=lo, x_hi=hi)
+        assert sample.shape[0] == npts
+        t = torch.from_numpy(sample).to(device)
+        st2 = st if npts <= st.capacity else psa.DeviceStages(npts, device)
+        st2.count_pairs(t)
+        st2.count_tests()
+        gpu_pairs, tests = st2.pairs(), st2.tests()
+        sample_desc = "x-slab cells [%d,%d] of the workload stream: %d points, %d tests" % (lo, hi, npts, tests)
+        ref_bin = os.path.join(ROOT, "oracle", "_ref", "main_timer")
+        if os.path.exists(ref_bin):
+            t0 = time.time()
+            r = subprocess.run([ref_bin, "-f", path, "-p", str(cores), "-c", str(cores)],
+                               capture_output=True, text=True, timeout=900)
+            wall = time.time() - t0
+            if r.returncode != 0:
+                return {"error": "reference binary failed rc=%d: %s" % (r.returncode, r.stderr[-200:])}
+            phases = {m.group(1): int(m.group(2)) / 1e6 for m in re.finditer(r"(\w+):\s+(\d+) us", r.stdout)}
+            count = int([ln for ln in r.stdout.splitlines() if ln.strip().isdigit()][-1])
+            return {"value": tests / phases["count"], "unit": "pairs-tested/s", "cores": cores, "kind": "reference",
+                    "sample": sample_desc, "phases_s": phases, "wall_s": wall, "pairs": count,
+                    "matches_hip_count": count == gpu_pairs,
+                    "value_whole_path": tests / (phases["parsing"] + phases["flatten"] + phases["count"]),
+                    "note": "value = tests / reference 'count' phase; value_whole_path also charges its "
+                            "parsing (tokenize+insert) and flatten phases"}
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        orc = oracle_lib.Oracle()
+        t0 = time.time()
+        pairs, tests2 = orc.count_pairs(sample, threads=cores)
+        wall = time.time() - t0
+        return {"value": tests / wall, "unit": "pairs-tested/s", "cores": cores, "kind": "port", "sample": sample_desc,
+                "wall_s": wall, "pairs": pairs, "matches_hip_count": pairs == gpu_pairs}
+    finally:
+        try:
+            os.remove(path)
+            os.rmdir(tmp)
+        except OSError:
+            pass
+
+
+if __name__ == "__main__":
+    main()

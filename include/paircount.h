@@ -139,6 +139,16 @@ int pc_count_pairs_device(const float *d_xyz, uint64_t n, int x_lo, int x_hi,
    for an unknown name or value. */
 int pc_set_variant(const char *name, int value);
 
+/* Per-kernel device timing for the stage functions above: while enabled, a
+   pair of HIP events is recorded on the launch stream around each kernel.
+   pc_profile_enable(1) also clears earlier samples.  pc_profile_read waits for
+   the recorded events and writes one text line per kernel:
+   "<kernel> <timed launches> <launches> <total ms of the timed launches>".
+   No counterpart in the reference (its -DTIMER phases, main.c:19-28, are the
+   closest; pc_phase_ms reports those). */
+int pc_profile_enable(int on);
+int pc_profile_read(char *buf, size_t buflen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,8 @@ ABI = [
     ("pc_count_tests_device", _i32, [_vp, _i32, _i32, _vp, _vp]),
     ("pc_count_pairs_device", _i32, [_vp, _u64, _i32, _i32, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     ("pc_set_variant", _i32, [_c.c_char_p, _i32]),
+    ("pc_profile_enable", _i32, [_i32]),
+    ("pc_profile_read", _i32, [_c.c_char_p, _sz]),
 ]
 
 
@@ -85,6 +87,21 @@ def _check(rc):
 
 def set_variant(name, value):
     _check(lib().pc_set_variant(name.encode(), int(value)))
+
+
+def profile_enable(on=True):
+    _check(lib().pc_profile_enable(1 if on else 0))
+
+
+def profile_read():
+    """{kernel: (timed_launches, launches, total_ms)} since the last profile_enable(True)."""
+    buf = ctypes.create_string_buffer(8192)
+    _check(lib().pc_profile_read(buf, len(buf)))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, timed, launches, ms = line.split()
+        out[name] = (int(timed), int(launches), float(ms))
+    return out
 
 
 def _host_ptr(arr):

@@ -11,6 +11,7 @@
 
 #include "pc_bin_atomic.h"
 #include "pc_count_global.h"
+#include "pc_count_tile.h"
 
 // ------------------------------------------------------------------ errors --
 static thread_local char g_err[512] = "";
@@ -37,7 +38,7 @@ extern "C" const char *pc_version(void) { return "1.0 gfx950"; }
 
 // ---------------------------------------------------------------- variants --
 static int g_variant_bin = 0;     // 0 = atomic counting sort
-static int g_variant_count = 0;   // 0 = global-memory pair test
+static int g_variant_count = 1;   // 0 = global-memory pair test, 1 = LDS-tiled pencil strips
 
 extern "C" int pc_set_variant(const char *name, int value)
 {
@@ -48,11 +49,95 @@ extern "C" int pc_set_variant(const char *name, int value)
         return PC_OK;
     }
     if (!strcmp(name, "count")) {
-        if (value != 0) return pc_fail(PC_ERR_ARG, "pc_set_variant: count variant %d unknown", value);
+        if (value < 0 || value > 1) return pc_fail(PC_ERR_ARG, "pc_set_variant: count variant %d unknown", value);
         g_variant_count = value;
         return PC_OK;
     }
     return pc_fail(PC_ERR_ARG, "pc_set_variant: unknown name '%s'", name);
+}
+
+// --------------------------------------------------------------- profiling --
+// Optional per-kernel timing: a pair of HIP events recorded on the launch stream
+// around each kernel.  Off by default; the first PC_PROF_RING launches of each
+// kernel after pc_profile_enable(1) are timed.
+#define PC_PROF_SLOTS 24
+#define PC_PROF_RING 512
+struct pc_prof_slot {
+    const char *name;
+    hipEvent_t ev[PC_PROF_RING][2];
+    int created, used;
+    unsigned long long launches;
+};
+static pc_prof_slot g_prof[PC_PROF_SLOTS];
+static int g_prof_n = 0, g_prof_on = 0;
+
+static pc_prof_slot *prof_slot(const char *name)
+{
+    for (int i = 0; i < g_prof_n; i++)
+        if (g_prof[i].name == name || !strcmp(g_prof[i].name, name)) return &g_prof[i];
+    if (g_prof_n == PC_PROF_SLOTS) return nullptr;
+    g_prof[g_prof_n].name = name;
+    return &g_prof[g_prof_n++];
+}
+
+struct pc_prof_scope {
+    pc_prof_slot *s = nullptr;
+    hipStream_t st;
+    int idx = -1;
+    pc_prof_scope(const char *name, hipStream_t stream) : st(stream)
+    {
+        if (!g_prof_on) return;
+        s = prof_slot(name);
+        if (!s) return;
+        s->launches++;
+        if (s->used == PC_PROF_RING) return;
+        if (s->used == s->created) {
+            if (hipEventCreate(&s->ev[s->created][0]) != hipSuccess) return;
+            if (hipEventCreate(&s->ev[s->created][1]) != hipSuccess) return;
+            s->created++;
+        }
+        idx = s->used++;
+        (void)hipEventRecord(s->ev[idx][0], st);
+    }
+    ~pc_prof_scope()
+    {
+        if (idx >= 0) (void)hipEventRecord(s->ev[idx][1], st);
+    }
+};
+
+#define PC_LAUNCH(name, kernel, grid, block, stream, ...)                          \
+    do {                                                                            \
+        pc_prof_scope prof_(name, stream);                                          \
+        hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);            \
+    } while (0)
+
+extern "C" int pc_profile_enable(int on)
+{
+    g_prof_on = on != 0;
+    if (on)
+        for (int i = 0; i < g_prof_n; i++) { g_prof[i].used = 0; g_prof[i].launches = 0; }
+    return PC_OK;
+}
+
+extern "C" int pc_profile_read(char *buf, size_t buflen)
+{
+    if (!buf || buflen == 0) return pc_fail(PC_ERR_ARG, "pc_profile_read: null buffer");
+    size_t off = 0;
+    buf[0] = 0;
+    for (int i = 0; i < g_prof_n; i++) {
+        pc_prof_slot &s = g_prof[i];
+        double total = 0;
+        for (int k = 0; k < s.used; k++) {
+            PC_HIP(hipEventSynchronize(s.ev[k][1]));
+            float ms = 0;
+            PC_HIP(hipEventElapsedTime(&ms, s.ev[k][0], s.ev[k][1]));
+            total += ms;
+        }
+        int w = snprintf(buf + off, buflen - off, "%s %d %llu %.6f\n", s.name, s.used, s.launches, total);
+        if (w < 0 || (size_t)w >= buflen - off) return pc_fail(PC_ERR_ARG, "pc_profile_read: buffer too small");
+        off += (size_t)w;
+    }
+    return PC_OK;
 }
 
 // ------------------------------------------------------------------ stages --
@@ -83,7 +168,7 @@ extern "C" int pc_cell_keys_device(const float *d_xyz, uint64_t n, uint32_t *d_k
     if (!d_status) return pc_fail(PC_ERR_ARG, "pc_cell_keys_device: null status");
     if (n > PC_MAX_POINTS) return pc_fail(PC_ERR_ARG, "pc_cell_keys_device: n too large");
     if (n == 0) return PC_OK;
-    hipLaunchKernelGGL(pc_keys_only, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+    PC_LAUNCH("pc_keys_only", pc_keys_only, dim3(grid_for(n, 256, 8192)), dim3(256), (hipStream_t)stream,
                        d_xyz, n, d_keys, d_status);
     PC_HIP(hipGetLastError());
     return PC_OK;
@@ -108,13 +193,13 @@ extern "C" int pc_bin_device(const float *d_xyz, uint64_t n, float *d_sorted_xyz
 
     PC_HIP(hipMemsetAsync(d_cell_start, 0, m * sizeof(uint32_t), s));
     if (n)
-        hipLaunchKernelGGL(pc_a1_keys_hist, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, d_xyz, n, keys,
+        PC_LAUNCH("pc_a1_keys_hist", pc_a1_keys_hist, dim3(grid_for(n, 256, 8192)), dim3(256), s, d_xyz, n, keys,
                            d_cell_start, d_status);
-    hipLaunchKernelGGL(pc_a2_scan_reduce, dim3(ntiles), dim3(PC_SCAN_TPB), 0, s, d_cell_start, m, sums);
-    hipLaunchKernelGGL(pc_a2_scan_spine, dim3(1), dim3(PC_SCAN_TPB), 0, s, sums, ntiles);
-    hipLaunchKernelGGL(pc_a2_scan_apply, dim3(ntiles), dim3(PC_SCAN_TPB), 0, s, d_cell_start, m, sums);
+    PC_LAUNCH("pc_a2_scan_reduce", pc_a2_scan_reduce, dim3(ntiles), dim3(PC_SCAN_TPB), s, d_cell_start, m, sums);
+    PC_LAUNCH("pc_a2_scan_spine", pc_a2_scan_spine, dim3(1), dim3(PC_SCAN_TPB), s, sums, ntiles);
+    PC_LAUNCH("pc_a2_scan_apply", pc_a2_scan_apply, dim3(ntiles), dim3(PC_SCAN_TPB), s, d_cell_start, m, sums);
     if (n)
-        hipLaunchKernelGGL(pc_a3_scatter, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, d_xyz, keys, n,
+        PC_LAUNCH("pc_a3_scatter", pc_a3_scatter, dim3(grid_for(n, 256, 8192)), dim3(256), s, d_xyz, keys, n,
                            d_cell_start, d_sorted_xyz);
     PC_HIP(hipGetLastError());
     return PC_OK;
@@ -137,10 +222,17 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
     int rc = check_slab("pc_count_sorted_device", x_lo, x_hi);
     if (rc) return rc;
     if (n == 0 || x_lo == x_hi) return PC_OK;
-    uint32_t c_lo = (uint32_t)x_lo * PC_NBB2, c_hi = (uint32_t)x_hi * PC_NBB2;
-    hipLaunchKernelGGL(pc_c0_count_global, dim3(grid_for(n, 256, 1 << 20)), dim3(256), 0,
-                       (hipStream_t)stream, d_sorted_xyz, d_cell_start, c_lo, c_hi,
-                       (unsigned long long *)d_npairs);
+    if (g_variant_count == 0) {
+        uint32_t c_lo = (uint32_t)x_lo * PC_NBB2, c_hi = (uint32_t)x_hi * PC_NBB2;
+        PC_LAUNCH("pc_c0_count_global", pc_c0_count_global, dim3(grid_for(n, 256, 1 << 20)), dim3(256), (hipStream_t)stream, d_sorted_xyz, d_cell_start, c_lo, c_hi,
+                           (unsigned long long *)d_npairs);
+    } else {
+        // 8 XCD groups x layers x (largest band of strips any group owns)
+        const int band = (PC_T_NS + 7) / 8;
+        const int grid = 8 * (x_hi - x_lo) * band;
+        PC_LAUNCH("pc_c1_count_tiles", pc_c1_count_tiles, dim3(grid), dim3(PC_T_TPB), (hipStream_t)stream,
+                           d_sorted_xyz, d_cell_start, x_lo, x_hi, (unsigned long long *)d_npairs);
+    }
     PC_HIP(hipGetLastError());
     return PC_OK;
 }
@@ -153,7 +245,7 @@ extern "C" int pc_count_tests_device(const uint32_t *d_cell_start, int x_lo, int
     if (rc) return rc;
     if (x_lo == x_hi) return PC_OK;
     uint32_t c_lo = (uint32_t)x_lo * PC_NBB2, c_hi = (uint32_t)x_hi * PC_NBB2;
-    hipLaunchKernelGGL(pc_count_tests, dim3(8192), dim3(256), 0, (hipStream_t)stream, d_cell_start, c_lo,
+    PC_LAUNCH("pc_count_tests", pc_count_tests, dim3(8192), dim3(256), (hipStream_t)stream, d_cell_start, c_lo,
                        c_hi, (unsigned long long *)d_ntests);
     PC_HIP(hipGetLastError());
     return PC_OK;
