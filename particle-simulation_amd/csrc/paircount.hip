@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include "pc_bin_atomic.h"
+#include "pc_bin_lds.h"
 #include "pc_count_global.h"
 #include "pc_count_tile.h"
 
@@ -37,14 +38,14 @@ extern "C" const char *pc_last_error(void) { return g_err; }
 extern "C" const char *pc_version(void) { return "1.0 gfx950"; }
 
 // ---------------------------------------------------------------- variants --
-static int g_variant_bin = 0;     // 0 = atomic counting sort
+static int g_variant_bin = 1;     // 0 = atomic counting sort, 1 = LDS-staged three-level bucket sort
 static int g_variant_count = 1;   // 0 = global-memory pair test, 1 = LDS-tiled pencil strips
 
 extern "C" int pc_set_variant(const char *name, int value)
 {
     if (!name) return pc_fail(PC_ERR_ARG, "pc_set_variant: null name");
     if (!strcmp(name, "bin")) {
-        if (value != 0) return pc_fail(PC_ERR_ARG, "pc_set_variant: bin variant %d unknown", value);
+        if (value < 0 || value > 1) return pc_fail(PC_ERR_ARG, "pc_set_variant: bin variant %d unknown", value);
         g_variant_bin = value;
         return PC_OK;
     }
@@ -145,12 +146,59 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static const uint64_t PC_MAX_POINTS = 0xFFFFFFF0ull;   // slots are uint32
 
 static inline uint32_t scan_tiles(uint64_t m) { return (uint32_t)((m + PC_SCAN_TILE - 1) / PC_SCAN_TILE); }
+static inline int grid_for(uint64_t n, int tpb, int cap);
+
+// uint32 counters of the LDS variant, after its N*12-byte temp array
+static const size_t LDS_WS_COUNTERS = PC_L_BINS + (PC_L_NPENCILS + 3) + 3 * PC_L_BINS + 2 * (PC_L_NPENCILS + 1);
 
 extern "C" size_t pc_workspace_bytes(uint64_t n)
 {
     size_t keys = align_up((size_t)n * 4 + 4, 256);
     size_t sums = align_up((size_t)scan_tiles(PC_NCELLS + 2) * 4, 256);
-    return keys + sums + 256;
+    size_t v0 = keys + sums + 256;
+    size_t v1 = align_up((size_t)n * 12 + 16, 256) + align_up(LDS_WS_COUNTERS * 4, 256) + 256;
+    return v0 > v1 ? v0 : v1;
+}
+
+static pc_lds_ws carve_lds_ws(void *ws, uint64_t n)
+{
+    pc_lds_ws w;
+    w.tmp = (float *)ws;
+    uint32_t *u = (uint32_t *)((char *)ws + align_up((size_t)n * 12 + 16, 256));
+    w.layer_count = u;            u += PC_L_BINS;
+    w.pencil_count = u;           u += PC_L_NPENCILS + 3;
+    w.layer_start = u;            u += PC_L_BINS;
+    w.layer_cursor = u;           u += PC_L_BINS;
+    w.layer_tile = u;             u += PC_L_BINS;
+    w.pencil_start = u;           u += PC_L_NPENCILS + 1;
+    w.pencil_cursor = u;
+    return w;
+}
+
+static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *table, void *ws,
+                   int32_t *d_status, hipStream_t s)
+{
+    pc_lds_ws w = carve_lds_ws(ws, n);
+    PC_HIP(hipMemsetAsync(w.layer_count, 0, (PC_L_BINS + PC_L_NPENCILS + 3) * sizeof(uint32_t), s));
+    const int tiles = (int)((n + PC_L_TILE - 1) / PC_L_TILE);
+    if (n) PC_LAUNCH("pc_l1_hist_x", pc_l1_hist_x, dim3(grid_for(n, PC_L_TPB * 8, 2048)), dim3(PC_L_TPB), s,
+                     d_xyz, n, w.layer_count, d_status);
+    PC_LAUNCH("pc_l2_scan_x", pc_l2_scan_x, dim3(1), dim3(512), s, w.layer_count, w.layer_start, w.layer_cursor,
+              w.layer_tile);
+    if (n) {
+        PC_LAUNCH("pc_l3_partition_x", pc_l36_partition<0>, dim3(tiles), dim3(PC_L_TPB), s, d_xyz, n, d_sorted,
+                  w.layer_start, w.layer_tile, w.layer_cursor);
+        PC_LAUNCH("pc_l4_hist_y", pc_l4_hist_y, dim3(tiles + PC_NBB), dim3(PC_L_TPB), s, d_sorted, w.layer_start,
+                  w.layer_tile, w.pencil_count, d_status);
+    }
+    PC_LAUNCH("pc_l5_scan_y", pc_l5_scan_y, dim3(1), dim3(1024), s, w.pencil_count, w.pencil_start, w.pencil_cursor);
+    if (n)
+        PC_LAUNCH("pc_l6_partition_y", pc_l36_partition<1>, dim3(tiles + PC_NBB), dim3(PC_L_TPB), s, d_sorted, n,
+                  w.tmp, w.layer_start, w.layer_tile, w.pencil_cursor);
+    PC_LAUNCH("pc_l7_sort_pencils", pc_l7_sort_pencils, dim3((PC_L_NPENCILS + PC_L7_WAVES - 1) / PC_L7_WAVES),
+              dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted, w.pencil_start, table, d_status);
+    PC_HIP(hipGetLastError());
+    return PC_OK;
 }
 
 static inline int grid_for(uint64_t n, int tpb, int cap)
@@ -186,6 +234,7 @@ extern "C" int pc_bin_device(const float *d_xyz, uint64_t n, float *d_sorted_xyz
         return pc_fail(PC_ERR_ARG, "pc_bin_device: workspace %zu < %zu bytes", workspace_bytes,
                        pc_workspace_bytes(n));
     hipStream_t s = (hipStream_t)stream;
+    if (g_variant_bin == 1) return bin_lds(d_xyz, n, d_sorted_xyz, d_cell_start, d_workspace, d_status, s);
     const uint64_t m = PC_NCELLS + 2;
     uint32_t *keys = (uint32_t *)d_workspace;
     uint32_t *sums = (uint32_t *)((char *)d_workspace + align_up((size_t)n * 4 + 4, 256));

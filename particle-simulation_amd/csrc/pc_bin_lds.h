@@ -1,0 +1,386 @@
+// Binning variant 1 ("lds"): most-significant-digit bucket sort in three levels
+// that follow the key's own structure (reference main.c:32, key = i*403^2 + j*403 + k):
+//
+//   level X  points -> 403 x layers      L1 histogram, L2 scan, L3 partition
+//   level Y  layer  -> 403 pencils (i,j) L4 histogram, L5 scan, L6 partition
+//   level Z  pencil -> 403 cells         L7: one wave sorts one pencil in LDS and
+//                                        writes its slice of the cell-start table
+//
+// Replaces insert/atomic_insert/flatten (reference hashmap.h:69-153) and supersedes
+// variant 0's per-point global atomics: every histogram and every slot claim is an
+// LDS atomic; global atomics are one per (tile, non-empty bin).  Each partition
+// pass sorts a tile of points by bin inside LDS and then writes every bin's run
+// with coalesced dword stores, so all three passes stream at HBM rate.
+//
+// Data movement per point: L1 12 B read; L3, L6, L7 12 B read + 12 B write each;
+// L4 12 B read  => 96 B/point, plus 4 B per cell of table written by L7.
+// The order of points inside a cell is unspecified (as in the reference).
+#pragma once
+#include "pc_device.h"
+
+#define PC_L_TPB 256
+#define PC_L_PPT 16
+#define PC_L_TILE (PC_L_TPB * PC_L_PPT)        // 4096 points = 48 KB of LDS
+#define PC_L_NPENCILS (PC_NBB * PC_NBB)        // 162409, padding pencils included
+#define PC_L_BINS 404
+
+// workspace carve-up (uint32 units after the N*12-byte temp array)
+struct pc_lds_ws {
+    float *tmp;               // N*3 floats
+    uint32_t *layer_count;    // [404]   zeroed each call   } contiguous, one memset
+    uint32_t *pencil_count;   // [162409+3] zeroed each call }
+    uint32_t *layer_start;    // [404]
+    uint32_t *layer_cursor;   // [404]
+    uint32_t *layer_tile;     // [404]  prefix of tiles per layer (levels Y)
+    uint32_t *pencil_start;   // [162409+1]
+    uint32_t *pencil_cursor;  // [162409+1]
+};
+
+// ---- L1: histogram of x layers ---------------------------------------------
+__global__ void __launch_bounds__(PC_L_TPB)
+pc_l1_hist_x(const float *__restrict__ xyz, uint64_t n, uint32_t *__restrict__ layer_count,
+             int32_t *__restrict__ status)
+{
+    __shared__ uint32_t h[PC_L_BINS];
+    for (int b = threadIdx.x; b < PC_L_BINS; b += PC_L_TPB) h[b] = 0;
+    __syncthreads();
+    bool bad = false;
+    const uint64_t stride = (uint64_t)gridDim.x * PC_L_TPB;
+    for (uint64_t p = (uint64_t)blockIdx.x * PC_L_TPB + threadIdx.x; p < n; p += stride) {
+        const int i = pc_cell_index(xyz[3 * p]);
+        if ((unsigned)i >= 400u) { bad = true; continue; }
+        atomicAdd(&h[i], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < 400; b += PC_L_TPB)
+        if (h[b]) atomicAdd(&layer_count[b], h[b]);
+    if (bad) atomicOr(status, 1);
+}
+
+// ---- L2: scan of the 403 layer counts (one workgroup) ------------------------
+__global__ void __launch_bounds__(512)
+pc_l2_scan_x(const uint32_t *__restrict__ layer_count, uint32_t *__restrict__ layer_start,
+             uint32_t *__restrict__ layer_cursor, uint32_t *__restrict__ layer_tile)
+{
+    __shared__ uint32_t a[512], t[512];
+    const int i = threadIdx.x;
+    const uint32_t c = i < PC_NBB ? layer_count[i] : 0u;
+    a[i] = c;
+    t[i] = (c + PC_L_TILE - 1) / PC_L_TILE;
+    __syncthreads();
+    for (int off = 1; off < 512; off <<= 1) {          // Hillis-Steele, inclusive
+        uint32_t va = i >= off ? a[i - off] : 0u, vt = i >= off ? t[i - off] : 0u;
+        __syncthreads();
+        a[i] += va;
+        t[i] += vt;
+        __syncthreads();
+    }
+    if (i < PC_L_BINS) {
+        const uint32_t ex = a[i] - c;
+        layer_start[i] = ex;
+        layer_cursor[i] = ex;
+        layer_tile[i] = t[i] - (c + PC_L_TILE - 1) / PC_L_TILE;
+    }
+}
+
+// Which layer does tile `b` of levels Y belong to?  layer_tile is the exclusive
+// prefix of tiles per layer; entry 403 holds the total.
+__device__ __forceinline__ int pc_find_layer(const uint32_t *__restrict__ layer_tile, uint32_t b)
+{
+    int lo = 0, hi = PC_NBB;                           // invariant: layer_tile[lo] <= b < layer_tile[hi]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (layer_tile[mid] <= b) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ---- L4: histogram of pencils inside each layer ------------------------------
+__global__ void __launch_bounds__(PC_L_TPB)
+pc_l4_hist_y(const float *__restrict__ pts, const uint32_t *__restrict__ layer_start,
+             const uint32_t *__restrict__ layer_tile, uint32_t *__restrict__ pencil_count,
+             int32_t *__restrict__ status)
+{
+    __shared__ uint32_t h[PC_L_BINS];
+    if (blockIdx.x >= layer_tile[PC_NBB]) return;
+    const int layer = pc_find_layer(layer_tile, blockIdx.x);
+    const uint32_t chunk = blockIdx.x - layer_tile[layer];
+    const uint32_t first = layer_start[layer] + chunk * PC_L_TILE;
+    const uint32_t stop = min(first + PC_L_TILE, layer_start[layer + 1]);
+    for (int b = threadIdx.x; b < PC_L_BINS; b += PC_L_TPB) h[b] = 0;
+    __syncthreads();
+    bool bad = false;
+    for (uint32_t p = first + threadIdx.x; p < stop; p += PC_L_TPB) {
+        const int j = pc_cell_index(pts[3 * (uint64_t)p + 1]);
+        if ((unsigned)j >= 400u) { bad = true; continue; }
+        atomicAdd(&h[j], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < 400; b += PC_L_TPB)
+        if (h[b]) atomicAdd(&pencil_count[layer * PC_NBB + b], h[b]);
+    if (bad) atomicOr(status, 1);
+}
+
+// ---- L5: scan of the pencil counts (one workgroup of 1024) -------------------
+__global__ void __launch_bounds__(1024)
+pc_l5_scan_y(const uint32_t *__restrict__ pencil_count, uint32_t *__restrict__ pencil_start,
+             uint32_t *__restrict__ pencil_cursor)
+{
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (PC_L_NPENCILS + 1 + 1023) / 1024;          // 159
+    const int b0 = t * per, b1 = min(b0 + per, PC_L_NPENCILS + 1);
+    uint32_t s = 0;
+    for (int b = b0; b < b1; b++) s += b < PC_L_NPENCILS ? pencil_count[b] : 0u;
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - s;
+    for (int b = b0; b < b1; b++) {
+        pencil_start[b] = run;
+        pencil_cursor[b] = run;
+        run += b < PC_L_NPENCILS ? pencil_count[b] : 0u;
+    }
+}
+
+// ---- L3 / L6: partition a tile of points into 403 bins -----------------------
+// LEVEL 0: tile = points [blockIdx*TILE, +TILE) of the input, bin = x cell,
+//          cursors = layer_cursor.
+// LEVEL 1: tile = a chunk of one layer, bin = y cell, cursors = that layer's
+//          row of pencil_cursor.
+template <int LEVEL>
+__global__ void __launch_bounds__(PC_L_TPB)
+pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ dst,
+                 const uint32_t *__restrict__ layer_start, const uint32_t *__restrict__ layer_tile,
+                 uint32_t *__restrict__ cursor)
+{
+    __shared__ float buf[PC_L_TILE * 3];              // raw tile, then the tile sorted by bin
+    __shared__ uint16_t bin_of[PC_L_TILE];
+    __shared__ uint32_t hist[PC_L_BINS];
+    __shared__ uint32_t lstart[PC_L_BINS];
+    __shared__ uint32_t delta[PC_L_BINS];             // global slot of bin's first point minus lstart
+    const int tid = threadIdx.x;
+
+    uint64_t first;
+    uint32_t cnt;
+    if (LEVEL == 0) {
+        first = (uint64_t)blockIdx.x * PC_L_TILE;
+        if (first >= n) return;
+        cnt = (uint32_t)min((uint64_t)PC_L_TILE, n - first);
+    } else {
+        if (blockIdx.x >= layer_tile[PC_NBB]) return;
+        const int layer = pc_find_layer(layer_tile, blockIdx.x);
+        const uint32_t chunk = blockIdx.x - layer_tile[layer];
+        first = (uint64_t)layer_start[layer] + (uint64_t)chunk * PC_L_TILE;
+        cnt = min((uint32_t)PC_L_TILE, layer_start[layer + 1] - (uint32_t)first);
+        cursor += layer * PC_NBB;
+    }
+    for (int b = tid; b < PC_L_BINS; b += PC_L_TPB) hist[b] = 0;
+    // raw tile -> LDS, coalesced dwords
+    const float *g = src + 3 * first;
+    for (uint32_t d = tid; d < 3 * cnt; d += PC_L_TPB) buf[d] = g[d];
+    __syncthreads();
+
+    // each thread: its points' bin and rank inside the bin (LDS atomic)
+    float px[PC_L_PPT], py[PC_L_PPT], pz[PC_L_PPT];
+    uint32_t tag[PC_L_PPT];                            // bin | rank << 10, or ~0 for "skip"
+#pragma unroll
+    for (int j = 0; j < PC_L_PPT; j++) {
+        const uint32_t i = tid + j * PC_L_TPB;
+        tag[j] = 0xFFFFFFFFu;
+        if (i < cnt) {
+            px[j] = buf[3 * i];
+            py[j] = buf[3 * i + 1];
+            pz[j] = buf[3 * i + 2];
+            const int b = pc_cell_index(LEVEL == 0 ? px[j] : py[j]);
+            if ((unsigned)b < 400u) tag[j] = (uint32_t)b | (atomicAdd(&hist[b], 1u) << 10);
+        }
+    }
+    __syncthreads();
+
+    // exclusive scan of the 404 bins by wave 0 (7 bins per lane), then claim
+    // global space: one atomic per non-empty bin
+    if (tid < 64) {
+        uint32_t c[7], s = 0;
+#pragma unroll
+        for (int q = 0; q < 7; q++) {
+            const int b = tid * 7 + q;
+            c[q] = b < PC_L_BINS ? hist[b] : 0u;
+            s += c[q];
+        }
+        uint32_t inc = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t v = __shfl_up(inc, off, 64);
+            if (tid >= off) inc += v;
+        }
+        uint32_t run = inc - s;
+#pragma unroll
+        for (int q = 0; q < 7; q++) {
+            const int b = tid * 7 + q;
+            if (b < PC_L_BINS) lstart[b] = run;
+            run += c[q];
+        }
+    }
+    __syncthreads();
+    for (int b = tid; b < PC_L_BINS; b += PC_L_TPB) {
+        const uint32_t c = hist[b];
+        if (c) delta[b] = atomicAdd(&cursor[b], c) - lstart[b];
+    }
+    // scatter into LDS in bin order (all raw reads happened before the barrier above)
+#pragma unroll
+    for (int j = 0; j < PC_L_PPT; j++) {
+        if (tag[j] != 0xFFFFFFFFu) {
+            const uint32_t b = tag[j] & 1023u, pos = lstart[b] + (tag[j] >> 10);
+            buf[3 * pos] = px[j];
+            buf[3 * pos + 1] = py[j];
+            buf[3 * pos + 2] = pz[j];
+            bin_of[pos] = (uint16_t)b;
+        }
+    }
+    __syncthreads();
+    // runs -> global, coalesced dwords
+    const uint32_t kept = lstart[PC_L_BINS - 1] + hist[PC_L_BINS - 1];
+    for (uint32_t d = tid; d < 3 * kept; d += PC_L_TPB) {
+        const uint32_t e = d / 3u;
+        const uint32_t slot = delta[bin_of[e]] + e;
+        dst[3 * (uint64_t)slot + (d - 3u * e)] = buf[d];
+    }
+}
+
+// Orders one wave's LDS traffic: LDS operations of a wave complete in issue
+// order, so draining the counter makes every lane's earlier LDS writes and
+// atomics visible to every lane's later reads.  No other wave touches this LDS.
+__device__ __forceinline__ void pc_wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- L7: one wave sorts one pencil by z cell and writes its table slice --------
+#define PC_L7_WAVES 4
+#define PC_L7_CAP 1024                                 // points a wave stages in LDS
+#define PC_L7_PPL (PC_L7_CAP / 64)
+
+__global__ void __launch_bounds__(PC_L7_WAVES * 64)
+pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
+                   const uint32_t *__restrict__ pencil_start, uint32_t *__restrict__ table,
+                   int32_t *__restrict__ status)
+{
+    __shared__ uint32_t hist_all[PC_L7_WAVES][PC_L_BINS];
+    __shared__ float stage_all[PC_L7_WAVES][PC_L7_CAP * 3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *hist = hist_all[wave];
+    float *stage = stage_all[wave];
+    const uint32_t pencil = blockIdx.x * PC_L7_WAVES + wave;
+    if (pencil >= PC_L_NPENCILS) return;
+    const uint32_t base = pencil_start[pencil], n = pencil_start[pencil + 1] - base;
+    uint32_t *slice = table + (uint64_t)pencil * PC_NBB;
+    if (pencil == PC_L_NPENCILS - 1 && lane < 2) table[(uint64_t)PC_L_NPENCILS * PC_NBB + lane] = base + n;
+    if (n == 0) {
+        for (int k = lane; k < PC_NBB; k += 64) slice[k] = base;
+        return;
+    }
+    for (int k = lane; k < PC_L_BINS; k += 64) hist[k] = 0;
+    pc_wave_lds_sync();
+    const float *g = src + 3 * (uint64_t)base;
+    bool bad = false;
+
+    if (n <= PC_L7_CAP) {
+        float px[PC_L7_PPL], py[PC_L7_PPL], pz[PC_L7_PPL];
+        uint32_t tag[PC_L7_PPL];
+#pragma unroll
+        for (int j = 0; j < PC_L7_PPL; j++) {
+            const uint32_t i = lane + 64 * j;
+            tag[j] = 0xFFFFFFFFu;
+            if (i < n) {
+                px[j] = g[3 * i]; py[j] = g[3 * i + 1]; pz[j] = g[3 * i + 2];
+                const int k = pc_cell_index(pz[j]);
+                if ((unsigned)k < 400u) tag[j] = (uint32_t)k | (atomicAdd(&hist[k], 1u) << 10);
+                else bad = true;
+            }
+        }
+        // wave-level exclusive scan of the bins
+        pc_wave_lds_sync();
+        uint32_t c[7], s = 0;
+#pragma unroll
+        for (int q = 0; q < 7; q++) {
+            const int b = lane * 7 + q;
+            c[q] = b < PC_L_BINS ? hist[b] : 0u;
+            s += c[q];
+        }
+        uint32_t inc = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t v = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += v;
+        }
+        uint32_t run = inc - s;
+#pragma unroll
+        for (int q = 0; q < 7; q++) {
+            const int b = lane * 7 + q;
+            if (b < PC_L_BINS) hist[b] = run;          // hist now holds the exclusive starts
+            run += c[q];
+        }
+        const uint32_t kept = __shfl(inc, 63, 64);
+        pc_wave_lds_sync();
+        for (int k = lane; k < PC_NBB; k += 64) slice[k] = base + hist[k];
+#pragma unroll
+        for (int j = 0; j < PC_L7_PPL; j++) {
+            if (tag[j] != 0xFFFFFFFFu) {
+                const uint32_t pos = hist[tag[j] & 1023u] + (tag[j] >> 10);
+                stage[3 * pos] = px[j]; stage[3 * pos + 1] = py[j]; stage[3 * pos + 2] = pz[j];
+            }
+        }
+        pc_wave_lds_sync();
+        float *o = dst + 3 * (uint64_t)base;
+        for (uint32_t d = lane; d < 3 * kept; d += 64) o[d] = stage[d];
+    } else {
+        // pencil larger than the staging buffer: histogram sweep, then a second
+        // sweep that scatters straight to global memory through LDS cursors
+        for (uint32_t i = lane; i < n; i += 64) {
+            const int k = pc_cell_index(g[3 * (uint64_t)i + 2]);
+            if ((unsigned)k < 400u) atomicAdd(&hist[k], 1u);
+            else bad = true;
+        }
+        pc_wave_lds_sync();
+        uint32_t c[7], s = 0;
+#pragma unroll
+        for (int q = 0; q < 7; q++) {
+            const int b = lane * 7 + q;
+            c[q] = b < PC_L_BINS ? hist[b] : 0u;
+            s += c[q];
+        }
+        uint32_t inc = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t v = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += v;
+        }
+        uint32_t run = inc - s;
+#pragma unroll
+        for (int q = 0; q < 7; q++) {
+            const int b = lane * 7 + q;
+            if (b < PC_L_BINS) hist[b] = run;
+            run += c[q];
+        }
+        pc_wave_lds_sync();
+        for (int k = lane; k < PC_NBB; k += 64) slice[k] = base + hist[k];
+        pc_wave_lds_sync();
+        float *o = dst + 3 * (uint64_t)base;
+        for (uint32_t i = lane; i < n; i += 64) {
+            const float x = g[3 * (uint64_t)i], y = g[3 * (uint64_t)i + 1], z = g[3 * (uint64_t)i + 2];
+            const int k = pc_cell_index(z);
+            if ((unsigned)k < 400u) {
+                const uint32_t pos = atomicAdd(&hist[k], 1u);
+                o[3 * (uint64_t)pos] = x; o[3 * (uint64_t)pos + 1] = y; o[3 * (uint64_t)pos + 2] = z;
+            }
+        }
+    }
+    if (bad) atomicOr(status, 1);
+}
