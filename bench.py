@@ -48,6 +48,13 @@ def kernel_bytes(name, n, layers):
         "pc_a3_scatter": 4 * n + 12 * n + 8 * n + 12 * n,   # key, xyz in, cursor rmw, xyz out
         "pc_c0_count_global": 12 * n + 4 * cells,
         "pc_c1_count_tiles": 12 * n + 4 * cells,
+        "pc_c2_count_waves": 12 * n + 4 * cells,
+        "pc_c3_count_groups": 12 * n + 4 * cells,
+        "pc_l1_hist_x": 12 * n,
+        "pc_l3_partition_x": 24 * n,
+        "pc_l4_hist_y": 12 * n,
+        "pc_l6_partition_y": 24 * n,
+        "pc_l7_sort_pencils": 24 * n + 4 * all_cells,
     }
     return table.get(name)
 

@@ -13,6 +13,8 @@
 #include "pc_bin_lds.h"
 #include "pc_count_global.h"
 #include "pc_count_tile.h"
+#include "pc_count_wave.h"
+#include "pc_count_group.h"
 
 // ------------------------------------------------------------------ errors --
 static thread_local char g_err[512] = "";
@@ -39,7 +41,7 @@ extern "C" const char *pc_version(void) { return "1.0 gfx950"; }
 
 // ---------------------------------------------------------------- variants --
 static int g_variant_bin = 1;     // 0 = atomic counting sort, 1 = LDS-staged three-level bucket sort
-static int g_variant_count = 1;   // 0 = global-memory pair test, 1 = LDS-tiled pencil strips
+static int g_variant_count = 3;   // 0 = global memory, 1 = LDS-tiled strips, 2 = wave per pencil, 3 = candidate-parallel groups
 
 extern "C" int pc_set_variant(const char *name, int value)
 {
@@ -50,7 +52,7 @@ extern "C" int pc_set_variant(const char *name, int value)
         return PC_OK;
     }
     if (!strcmp(name, "count")) {
-        if (value < 0 || value > 1) return pc_fail(PC_ERR_ARG, "pc_set_variant: count variant %d unknown", value);
+        if (value < 0 || value > 3) return pc_fail(PC_ERR_ARG, "pc_set_variant: count variant %d unknown", value);
         g_variant_count = value;
         return PC_OK;
     }
@@ -191,7 +193,8 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
         PC_LAUNCH("pc_l4_hist_y", pc_l4_hist_y, dim3(tiles + PC_NBB), dim3(PC_L_TPB), s, d_sorted, w.layer_start,
                   w.layer_tile, w.pencil_count, d_status);
     }
-    PC_LAUNCH("pc_l5_scan_y", pc_l5_scan_y, dim3(1), dim3(1024), s, w.pencil_count, w.pencil_start, w.pencil_cursor);
+    PC_LAUNCH("pc_l5_scan_y", pc_l5_scan_y, dim3(PC_NBB), dim3(512), s, w.pencil_count, w.layer_start,
+              w.pencil_start, w.pencil_cursor);
     if (n)
         PC_LAUNCH("pc_l6_partition_y", pc_l36_partition<1>, dim3(tiles + PC_NBB), dim3(PC_L_TPB), s, d_sorted, n,
                   w.tmp, w.layer_start, w.layer_tile, w.pencil_cursor);
@@ -275,6 +278,14 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
         uint32_t c_lo = (uint32_t)x_lo * PC_NBB2, c_hi = (uint32_t)x_hi * PC_NBB2;
         PC_LAUNCH("pc_c0_count_global", pc_c0_count_global, dim3(grid_for(n, 256, 1 << 20)), dim3(256), (hipStream_t)stream, d_sorted_xyz, d_cell_start, c_lo, c_hi,
                            (unsigned long long *)d_npairs);
+    } else if (g_variant_count == 3) {
+        const int grid = 8 * (x_hi - x_lo) * PC_G_WG_PER_BAND;
+        PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
+                  d_sorted_xyz, d_cell_start, x_lo, x_hi, (unsigned long long *)d_npairs);
+    } else if (g_variant_count == 2) {
+        const int grid = 8 * (x_hi - x_lo) * PC_W_WG_PER_BAND;
+        PC_LAUNCH("pc_c2_count_waves", pc_c2_count_waves, dim3(grid), dim3(PC_W_WAVES * 64), (hipStream_t)stream,
+                  d_sorted_xyz, d_cell_start, x_lo, x_hi, (unsigned long long *)d_npairs);
     } else {
         // 8 XCD groups x layers x (largest band of strips any group owns)
         const int band = (PC_T_NS + 7) / 8;

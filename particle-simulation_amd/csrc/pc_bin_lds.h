@@ -121,31 +121,30 @@ pc_l4_hist_y(const float *__restrict__ pts, const uint32_t *__restrict__ layer_s
     if (bad) atomicOr(status, 1);
 }
 
-// ---- L5: scan of the pencil counts (one workgroup of 1024) -------------------
-__global__ void __launch_bounds__(1024)
-pc_l5_scan_y(const uint32_t *__restrict__ pencil_count, uint32_t *__restrict__ pencil_start,
-             uint32_t *__restrict__ pencil_cursor)
+// ---- L5: scan of the pencil counts, one workgroup per layer -------------------
+// A layer's pencils start where the layer starts (known from L2), so the 403
+// rows scan independently: pencil_start[i*403+j] = layer_start[i] + sum_{j'<j}.
+__global__ void __launch_bounds__(512)
+pc_l5_scan_y(const uint32_t *__restrict__ pencil_count, const uint32_t *__restrict__ layer_start,
+             uint32_t *__restrict__ pencil_start, uint32_t *__restrict__ pencil_cursor)
 {
-    __shared__ uint32_t part[1024];
-    const int t = threadIdx.x;
-    const int per = (PC_L_NPENCILS + 1 + 1023) / 1024;          // 159
-    const int b0 = t * per, b1 = min(b0 + per, PC_L_NPENCILS + 1);
-    uint32_t s = 0;
-    for (int b = b0; b < b1; b++) s += b < PC_L_NPENCILS ? pencil_count[b] : 0u;
-    part[t] = s;
+    __shared__ uint32_t a[512];
+    const int j = threadIdx.x, layer = blockIdx.x;
+    const uint32_t c = j < PC_NBB ? pencil_count[layer * PC_NBB + j] : 0u;
+    a[j] = c;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t v = t >= off ? part[t - off] : 0u;
+    for (int off = 1; off < 512; off <<= 1) {
+        uint32_t v = j >= off ? a[j - off] : 0u;
         __syncthreads();
-        part[t] += v;
+        a[j] += v;
         __syncthreads();
     }
-    uint32_t run = part[t] - s;
-    for (int b = b0; b < b1; b++) {
-        pencil_start[b] = run;
-        pencil_cursor[b] = run;
-        run += b < PC_L_NPENCILS ? pencil_count[b] : 0u;
+    const uint32_t ex = layer_start[layer] + a[j] - c;
+    if (j < PC_NBB) {
+        pencil_start[layer * PC_NBB + j] = ex;
+        pencil_cursor[layer * PC_NBB + j] = ex;
     }
+    if (layer == PC_NBB - 1 && j == PC_NBB) pencil_start[PC_L_NPENCILS] = ex;   // total
 }
 
 // ---- L3 / L6: partition a tile of points into 403 bins -----------------------
@@ -251,15 +250,6 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
         const uint32_t slot = delta[bin_of[e]] + e;
         dst[3 * (uint64_t)slot + (d - 3u * e)] = buf[d];
     }
-}
-
-// Orders one wave's LDS traffic: LDS operations of a wave complete in issue
-// order, so draining the counter makes every lane's earlier LDS writes and
-// atomics visible to every lane's later reads.  No other wave touches this LDS.
-__device__ __forceinline__ void pc_wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
 }
 
 // ---- L7: one wave sorts one pencil by z cell and writes its table slice --------

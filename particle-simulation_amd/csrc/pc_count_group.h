@@ -1,0 +1,228 @@
+// Pair test, variant 3 ("group"): one wavefront owns one home pencil; lanes are
+// spread over CANDIDATES, not over home particles.
+//
+// Replaces counter_thread/compare/count_chunk/dist2 (reference main.c:85-91,
+// 161-234).  For home pencil (i,j), the 13 forward neighbour cells of (i,j,k)
+// (main.c:195-209) are cells k-1..k+1 of the pencils (i,j+1) (i+1,j-1) (i+1,j)
+// (i+1,j+1) -- "rows 1-4" -- plus cell k+1 of the home pencil ("row 0").
+//
+// The wave walks its pencil in windows of up to 64 z cells, lane t owning cell
+// t of the window for all bookkeeping (table reads, prefix sums, copies).  The
+// points of rows 1-4 are copied to LDS MERGED CELL-MAJOR (cell t's points of all
+// four rows are adjacent), so the candidates of a home particle in cell k are
+// ONE contiguous LDS range: cells k-1..k+1 of the merged array.  A group of G
+// lanes then takes one home particle and the group's lanes take 4 candidates
+// each (two packed pairs: v_pk_add/mul_f32), so a wave tests 64/G home particles
+// per step with no per-lane loops and no divergence; G is picked per window from
+// the mean range length.  Same-pencil pairs (later points of the cell, and cell
+// k+1 of row 0: main.c:215-221 and offset (0,0,1)) are few and are counted by a
+// short lane-per-home-particle loop.  A home cell whose candidates do not fit
+// the LDS buffer is counted against buffer-sized pieces of its candidate ranges.
+//
+// Hit counts come from compare masks (ballot + popcount on the scalar unit);
+// one 64-bit atomic per workgroup.  Workgroup -> pencil mapping is XCD-aware as
+// in variant 2 (speed only).
+#pragma once
+#include "pc_device.h"
+
+#define PC_G_WAVES 4
+#define PC_G_CAPM 448                   // merged candidates (rows 1-4) per window
+#define PC_G_CAPH 160                   // row-0 points per window
+#define PC_G_BAND (PC_NLAYERS / 8)
+#define PC_G_WG_PER_BAND ((PC_G_BAND + PC_G_WAVES - 1) / PC_G_WAVES)
+
+typedef float pc_v2f __attribute__((ext_vector_type(2)));
+
+struct pc_group_lds {
+    float x[PC_G_CAPM], y[PC_G_CAPM], z[PC_G_CAPM];   // merged rows 1-4 (reads may run past the end into h[])
+    float4 h[PC_G_CAPH];                               // row 0: home cells and the cell above
+    uint2 meta[PC_G_CAPH];                             // per home particle: .x = lo | hi<<16 (merged range), .y = end of its row-0 range
+};
+
+// One step of the candidate-parallel test: the wave handles 64/G home particles
+// [base, base+64/G); lane j of a group tests merged candidates lo+j+c*G, c=0..3,
+// and loops in strides of 4G while any group has candidates left.
+template <int G>
+__device__ __forceinline__ uint32_t pc_g_steps(const pc_group_lds &L, uint32_t nh, int lane)
+{
+    uint32_t hits = 0;
+    const uint32_t j = lane & (G - 1), grp = lane / G;
+    for (uint32_t base = 0; base < nh; base += 64 / G) {
+        const uint32_t hp = base + grp;
+        const bool live = hp < nh;
+        const uint2 m = L.meta[live ? hp : nh - 1];
+        const float4 a = L.h[live ? hp : nh - 1];
+        const uint32_t lo = m.x & 0xFFFFu, hi = live ? (m.x >> 16) : 0u;
+        const pc_v2f ax = {a.x, a.x}, ay = {a.y, a.y}, az = {a.z, a.z};
+        for (uint32_t p = lo + j;; p += 4 * G) {
+            const pc_v2f x01 = {L.x[p], L.x[p + G]}, x23 = {L.x[p + 2 * G], L.x[p + 3 * G]};
+            const pc_v2f y01 = {L.y[p], L.y[p + G]}, y23 = {L.y[p + 2 * G], L.y[p + 3 * G]};
+            const pc_v2f z01 = {L.z[p], L.z[p + G]}, z23 = {L.z[p + 2 * G], L.z[p + 3 * G]};
+            // (dx*dx + dy*dy) + dz*dz, each step rounded separately (no contraction: see build flags)
+            const pc_v2f dx01 = ax - x01, dy01 = ay - y01, dz01 = az - z01;
+            const pc_v2f dx23 = ax - x23, dy23 = ay - y23, dz23 = az - z23;
+            const pc_v2f s01 = (dx01 * dx01 + dy01 * dy01) + dz01 * dz01;
+            const pc_v2f s23 = (dx23 * dx23 + dy23 * dy23) + dz23 * dz23;
+            hits += __popcll(__ballot((s01.x <= 0.0025f) & (p < hi)));
+            hits += __popcll(__ballot((s01.y <= 0.0025f) & (p + G < hi)));
+            hits += __popcll(__ballot((s23.x <= 0.0025f) & (p + 2 * G < hi)));
+            hits += __popcll(__ballot((s23.y <= 0.0025f) & (p + 3 * G < hi)));
+            if (!__any(p + 4 * G - j < hi)) break;       // group-uniform: lo + done < hi
+        }
+    }
+    return hits;    // wave-uniform (every lane holds the wave total)
+}
+
+__global__ void __launch_bounds__(PC_G_WAVES * 64)
+pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T, int x_lo, int x_hi,
+                   unsigned long long *__restrict__ out)
+{
+    __shared__ pc_group_lds lds_all[PC_G_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    pc_group_lds &L = lds_all[wave];
+    unsigned long long acc = 0;          // per-lane partial (lane 0 also carries the wave-uniform hit counts)
+
+    const int g = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int layer = x_lo + q / PC_G_WG_PER_BAND;
+    const int jb = (q % PC_G_WG_PER_BAND) * PC_G_WAVES + wave;
+    const int j = g * PC_G_BAND + jb;
+    if (layer < x_hi && jb < PC_G_BAND) {
+        // table bases of the five rows; invalid rows (outside the occupied grid) are empty
+        const int ri[5] = {layer, layer, layer + 1, layer + 1, layer + 1};
+        const int rj[5] = {j, j + 1, j - 1, j, j + 1};
+        uint32_t tb[5];
+        bool valid[5];
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            valid[r] = ri[r] < PC_NLAYERS && rj[r] >= 0 && rj[r] < PC_NLAYERS;
+            tb[r] = valid[r] ? ((uint32_t)ri[r] * PC_NBB + rj[r]) * PC_NBB : 0u;
+        }
+        const uint32_t home_lo = T[tb[0]], home_hi = T[tb[0] + PC_NBB];
+        int z0 = 0;
+        uint32_t done = home_lo;         // first home slot not yet processed
+        while (done != home_hi && z0 < PC_NLAYERS) {
+            const int zl = z0 > 0 ? z0 - 1 : 0;
+            const int th0 = z0 - zl;                       // window index of the first home cell (0 or 1)
+            // ---- lane t owns window cell c = zl + t: per-row starts and counts
+            const int c = min(zl + lane, PC_NBB - 1);
+            uint32_t s[5], n[5];
+#pragma unroll
+            for (int r = 0; r < 5; r++) {
+                const uint32_t a0 = T[tb[r] + c], a1 = T[tb[r] + c + 1];
+                s[r] = valid[r] ? a0 : 0u;
+                n[r] = (valid[r] && zl + lane < PC_NBB - 1) ? a1 - a0 : 0u;
+            }
+            if (lane < th0) n[0] = 0;                      // row-0 points below the first home cell are not needed
+            const uint32_t nm = n[1] + n[2] + n[3] + n[4];
+            uint32_t cum_m = nm, cum_h = n[0];             // inclusive prefix sums over the window cells
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t vm = __shfl_up(cum_m, off, 64), vh = __shfl_up(cum_h, off, 64);
+                if (lane >= off) { cum_m += vm; cum_h += vh; }
+            }
+            // longest window that fits both buffers (feasible lanes form a prefix)
+            const int nfit = __popcll(__ballot(cum_m <= PC_G_CAPM && cum_h <= PC_G_CAPH));
+            const int t_last = nfit - 1;                   // last window cell; home cells are th0 .. t_last-1
+
+            if (t_last >= th0 + 1) {
+                const uint32_t tot_m = __shfl(cum_m, t_last, 64);
+                const uint32_t tot_h = __shfl(cum_h, t_last, 64);          // row-0 points staged (home cells + cell above)
+                const uint32_t nh = __shfl(cum_h, t_last - 1, 64);         // home particles in this window
+                const uint32_t h_first = __shfl(s[0], th0, 64);            // global slot of the first staged row-0 point
+                const uint32_t ex_m = cum_m - nm, ex_h = cum_h - n[0];
+                const uint32_t lo_m = __shfl_up(ex_m, 1, 64);              // start of cell t-1 in the merged array
+                const uint32_t hi_m = __shfl_down(cum_m, 1, 64);           // end of cell t+1
+                const uint32_t hi_h = __shfl_down(cum_h, 1, 64);           // end of cell t+1 in h[]
+                if (nh != 0) {
+                    // ---- merged copy of rows 1-4: lane t copies its cell's points
+                    if (lane <= t_last) {
+                        uint32_t dst = ex_m;
+#pragma unroll
+                        for (int r = 1; r < 5; r++) {
+                            for (uint32_t u = 0; u < n[r]; u++) {
+                                const float *p = pts + 3 * (uint64_t)(s[r] + u);
+                                L.x[dst + u] = p[0]; L.y[dst + u] = p[1]; L.z[dst + u] = p[2];
+                            }
+                            dst += n[r];
+                        }
+                    }
+                    // ---- row 0: one contiguous run, all lanes
+                    for (uint32_t e = lane; e < tot_h; e += 64) {
+                        const float *p = pts + 3 * (uint64_t)(h_first + e);
+                        L.h[e] = make_float4(p[0], p[1], p[2], 0.0f);
+                    }
+                    // ---- per home particle: its merged candidate range and the end of its row-0 range
+                    if (lane >= th0 && lane < t_last) {
+                        const uint32_t lo = lane > 0 ? lo_m : 0u;
+                        for (uint32_t u = 0; u < n[0]; u++) L.meta[ex_h + u] = make_uint2(lo | (hi_m << 16), hi_h);
+                    }
+                    pc_wave_lds_sync();
+                    // ---- rows 1-4: candidate-parallel steps, group size from the mean range length
+                    // slots = 4G should cover mean + 2 sigma of a Poisson range length:
+                    // m + 2*sqrt(m) + 1 <= 8, 16, 32, 64, 128  <=>  m <= 3, 9, 22, 49, 106
+                    const uint32_t mean3 = 3u * tot_m / (uint32_t)(t_last + 1);
+                    uint32_t hits;
+                    if (mean3 <= 3) hits = pc_g_steps<2>(L, nh, lane);
+                    else if (mean3 <= 9) hits = pc_g_steps<4>(L, nh, lane);
+                    else if (mean3 <= 22) hits = pc_g_steps<8>(L, nh, lane);
+                    else if (mean3 <= 49) hits = pc_g_steps<16>(L, nh, lane);
+                    else if (mean3 <= 106) hits = pc_g_steps<32>(L, nh, lane);
+                    else hits = pc_g_steps<64>(L, nh, lane);
+                    if (lane == 0) acc += hits;
+                    // ---- row 0: later points of the same cell and the cell above
+                    for (uint32_t hp = lane; hp < nh; hp += 64) {
+                        const float4 me = L.h[hp];
+                        const uint32_t end = L.meta[hp].y;
+                        uint32_t cnt = 0;
+                        for (uint32_t k2 = hp + 1; k2 < end; k2++) {
+                            const float4 v = L.h[k2];
+                            cnt += pc_hit(me.x, me.y, me.z, v.x, v.y, v.z);
+                        }
+                        acc += cnt;
+                    }
+                    pc_wave_lds_sync();
+                }
+                done = __shfl(s[0], t_last, 64);           // start of the last window cell = next first home cell
+                z0 = zl + t_last;
+            } else {
+                // ---- home cell z0 with its neighbours does not fit: stream the
+                //      candidate ranges through LDS in pieces ---------------------
+                const uint32_t h0 = __shfl(s[0], th0, 64);
+                const uint32_t h1 = h0 + __shfl(n[0], th0, 64);
+                uint32_t c_lo[5], c_hi[5];
+#pragma unroll
+                for (int r = 0; r < 5; r++) {
+                    // rows 1-4: cells z0-1..z0+1 ; row 0: cells z0 (later slots) and z0+1
+                    c_lo[r] = r == 0 ? h0 : __shfl(s[r], 0, 64);
+                    const int te = min(th0 + 1, 63);
+                    c_hi[r] = __shfl(s[r], te, 64) + __shfl(n[r], te, 64);
+                }
+#pragma unroll
+                for (int r = 0; r < 5; r++) {
+                    if (h0 == h1) break;                   // no home particle in this cell
+                    for (uint32_t p0 = c_lo[r]; p0 < c_hi[r]; p0 += PC_G_CAPM) {
+                        const uint32_t cnt = min((uint32_t)PC_G_CAPM, c_hi[r] - p0);
+                        for (uint32_t e = lane; e < cnt; e += 64) {
+                            const float *p = pts + 3 * (uint64_t)(p0 + e);
+                            L.x[e] = p[0]; L.y[e] = p[1]; L.z[e] = p[2];
+                        }
+                        pc_wave_lds_sync();
+                        for (uint32_t i = h0 + lane; i < h1; i += 64) {
+                            const float *p = pts + 3 * (uint64_t)i;
+                            const float x = p[0], y = p[1], z = p[2];
+                            uint32_t k2 = 0;
+                            if (r == 0 && i + 1 > p0) k2 = min(i + 1 - p0, cnt);   // row 0: only slots after i
+                            uint32_t hc = 0;
+                            for (; k2 < cnt; k2++) hc += pc_hit(x, y, z, L.x[k2], L.y[k2], L.z[k2]);
+                            acc += hc;
+                        }
+                        pc_wave_lds_sync();
+                    }
+                }
+                done = h1;
+                z0 += 1;
+            }
+        }
+    }
+    pc_block_add_u64<PC_G_WAVES>(acc, out);
+}

@@ -40,6 +40,15 @@ __device__ __forceinline__ bool pc_hit(float xi, float yi, float zi, float xj, f
     return s <= 0.0025f;
 }
 
+// Orders one wave's LDS traffic: LDS operations of a wave complete in issue
+// order, so draining the counter makes every lane's earlier LDS writes and
+// atomics visible to every lane's later reads.  No other wave touches this LDS.
+__device__ __forceinline__ void pc_wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Sum of a 32-bit value over the wave (DPP row ops + cross-row broadcast).
 __device__ __forceinline__ uint32_t pc_wave_sum(uint32_t v)
 {

@@ -27,10 +27,10 @@ def dev(torch_mod, a):
     return torch_mod.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to("cuda:0")
 
 
-VARIANTS = [(0, 0), (1, 1), (0, 1), (1, 0)]      # (binning variant, pair-test variant)
+VARIANTS = [(1, 3), (0, 0), (1, 1), (0, 2)]      # (binning variant, pair-test variant)
 
 
-def gpu_count(psa, stages, torch_mod, xyz, x_lo=0, x_hi=400, bin_v=1, count_v=1):
+def gpu_count(psa, stages, torch_mod, xyz, x_lo=0, x_hi=400, bin_v=1, count_v=3):
     psa.set_variant("bin", bin_v)
     psa.set_variant("count", count_v)
     t = dev(torch_mod, xyz).reshape(-1, 3)

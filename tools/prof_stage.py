@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Runs one stage of the hot path a few times on synthetic input; meant to sit
+behind `rocprofv3 --pmc ... -- python3 tools/prof_stage.py ...` so that the
+counter pass sees only a handful of dispatches.
+
+    python3 tools/prof_stage.py [--workload uniform100m] [--stage count|bin|all] [--reps 3]
+"""
+import argparse
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="uniform100m")
+    ap.add_argument("--stage", default="all", choices=["count", "bin", "all"])
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--bin-variant", type=int, default=None)
+    ap.add_argument("--count-variant", type=int, default=None)
+    args = ap.parse_args()
+    import torch
+    from __graft_entry__ import load_package
+    import bench
+    psa = load_package()
+    ht = importlib.import_module("particle_simulation_amd.hosttools")
+    kind_name, points, sigma, _ = bench.WORKLOADS[args.workload]
+    kind = ht.UNIFORM if kind_name == "uniform" else ht.BLOBS
+    if args.bin_variant is not None:
+        psa.set_variant("bin", args.bin_variant)
+    if args.count_variant is not None:
+        psa.set_variant("count", args.count_variant)
+    xyz = torch.from_numpy(ht.generate(kind, 7, points, sigma)).to("cuda:0")
+    st = psa.DeviceStages(points, "cuda:0")
+    n = st.bin(xyz)
+    torch.cuda.synchronize()
+    for _ in range(args.reps):
+        if args.stage in ("bin", "all"):
+            st.bin(xyz)
+        if args.stage in ("count", "all"):
+            st.count_sorted(n)
+    torch.cuda.synchronize()
+    print("pairs", st.pairs())
+
+
+if __name__ == "__main__":
+    main()
