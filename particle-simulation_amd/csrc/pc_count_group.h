@@ -32,6 +32,7 @@
 #define PC_G_WG_PER_BAND ((PC_G_BAND + PC_G_WAVES - 1) / PC_G_WAVES)
 
 typedef float pc_v2f __attribute__((ext_vector_type(2)));
+struct pc_f3 { float x, y, z; };          // one point as stored in the sorted array (12 bytes, 4-byte aligned)
 
 struct pc_group_lds {
     float x[PC_G_CAPM], y[PC_G_CAPM], z[PC_G_CAPM];   // merged rows 1-4 (reads may run past the end into h[])
@@ -47,14 +48,16 @@ __device__ __forceinline__ uint32_t pc_g_steps(const pc_group_lds &L, uint32_t n
 {
     uint32_t hits = 0;
     const uint32_t j = lane & (G - 1), grp = lane / G;
+    nh = __builtin_amdgcn_readfirstlane(nh);             // wave-uniform: keep the step loop scalar
     for (uint32_t base = 0; base < nh; base += 64 / G) {
-        const uint32_t hp = base + grp;
-        const bool live = hp < nh;
-        const uint2 m = L.meta[live ? hp : nh - 1];
-        const float4 a = L.h[live ? hp : nh - 1];
-        const uint32_t lo = m.x & 0xFFFFu, hi = live ? (m.x >> 16) : 0u;
+        const uint32_t hp = min(base + grp, nh - 1);
+        const uint2 m = L.meta[hp];
+        const float4 a = L.h[hp];
+        uint32_t p = (m.x & 0xFFFFu) + j;
+        // candidates this lane still has to test, counted in units of one: slot c is live iff rem > c*G
+        int rem = base + grp < nh ? (int)(m.x >> 16) - (int)p : 0;
         const pc_v2f ax = {a.x, a.x}, ay = {a.y, a.y}, az = {a.z, a.z};
-        for (uint32_t p = lo + j;; p += 4 * G) {
+        for (;;) {
             const pc_v2f x01 = {L.x[p], L.x[p + G]}, x23 = {L.x[p + 2 * G], L.x[p + 3 * G]};
             const pc_v2f y01 = {L.y[p], L.y[p + G]}, y23 = {L.y[p + 2 * G], L.y[p + 3 * G]};
             const pc_v2f z01 = {L.z[p], L.z[p + G]}, z23 = {L.z[p + 2 * G], L.z[p + 3 * G]};
@@ -63,11 +66,15 @@ __device__ __forceinline__ uint32_t pc_g_steps(const pc_group_lds &L, uint32_t n
             const pc_v2f dx23 = ax - x23, dy23 = ay - y23, dz23 = az - z23;
             const pc_v2f s01 = (dx01 * dx01 + dy01 * dy01) + dz01 * dz01;
             const pc_v2f s23 = (dx23 * dx23 + dy23 * dy23) + dz23 * dz23;
-            hits += __popcll(__ballot((s01.x <= 0.0025f) & (p < hi)));
-            hits += __popcll(__ballot((s01.y <= 0.0025f) & (p + G < hi)));
-            hits += __popcll(__ballot((s23.x <= 0.0025f) & (p + 2 * G < hi)));
-            hits += __popcll(__ballot((s23.y <= 0.0025f) & (p + 3 * G < hi)));
-            if (!__any(p + 4 * G - j < hi)) break;       // group-uniform: lo + done < hi
+            // one ballot per compare, masks combined on the scalar unit (a ballot of
+            // "a && b" would be materialised through a 0/1 VGPR and compared again)
+            hits += __popcll(__builtin_amdgcn_ballot_w64(s01.x <= 0.0025f) & __builtin_amdgcn_ballot_w64(rem > 0));
+            hits += __popcll(__builtin_amdgcn_ballot_w64(s01.y <= 0.0025f) & __builtin_amdgcn_ballot_w64(rem > G));
+            hits += __popcll(__builtin_amdgcn_ballot_w64(s23.x <= 0.0025f) & __builtin_amdgcn_ballot_w64(rem > 2 * G));
+            hits += __popcll(__builtin_amdgcn_ballot_w64(s23.y <= 0.0025f) & __builtin_amdgcn_ballot_w64(rem > 3 * G));
+            rem -= 4 * G;
+            p += 4 * G;
+            if (__builtin_amdgcn_ballot_w64(rem > 0) == 0) break;
         }
     }
     return hits;    // wave-uniform (every lane holds the wave total)
@@ -100,31 +107,46 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
         const uint32_t home_lo = T[tb[0]], home_hi = T[tb[0] + PC_NBB];
         int z0 = 0;
         uint32_t done = home_lo;         // first home slot not yet processed
+        // table entries of the current window: lane t holds, per row, the start of
+        // cell zl+t and of the cell after it.  The next window's entries are
+        // requested as soon as its position is known, so they arrive while the
+        // current window is being processed.
+        uint32_t a0[5], a1[5];
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const int c = min(lane, PC_NBB - 1);
+            a0[r] = T[tb[r] + c];
+            a1[r] = T[tb[r] + c + 1];
+        }
         while (done != home_hi && z0 < PC_NLAYERS) {
             const int zl = z0 > 0 ? z0 - 1 : 0;
             const int th0 = z0 - zl;                       // window index of the first home cell (0 or 1)
-            // ---- lane t owns window cell c = zl + t: per-row starts and counts
-            const int c = min(zl + lane, PC_NBB - 1);
+            // ---- lane t owns window cell zl + t: per-row starts and counts
             uint32_t s[5], n[5];
 #pragma unroll
             for (int r = 0; r < 5; r++) {
-                const uint32_t a0 = T[tb[r] + c], a1 = T[tb[r] + c + 1];
-                s[r] = valid[r] ? a0 : 0u;
-                n[r] = (valid[r] && zl + lane < PC_NBB - 1) ? a1 - a0 : 0u;
+                s[r] = valid[r] ? a0[r] : 0u;
+                n[r] = (valid[r] && zl + lane < PC_NBB - 1) ? a1[r] - a0[r] : 0u;
             }
             if (lane < th0) n[0] = 0;                      // row-0 points below the first home cell are not needed
             const uint32_t nm = n[1] + n[2] + n[3] + n[4];
-            uint32_t cum_m = nm, cum_h = n[0];             // inclusive prefix sums over the window cells
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t vm = __shfl_up(cum_m, off, 64), vh = __shfl_up(cum_h, off, 64);
-                if (lane >= off) { cum_m += vm; cum_h += vh; }
-            }
+            const uint32_t cum_m = pc_wave_incl_scan(nm), cum_h = pc_wave_incl_scan(n[0]);
             // longest window that fits both buffers (feasible lanes form a prefix)
-            const int nfit = __popcll(__ballot(cum_m <= PC_G_CAPM && cum_h <= PC_G_CAPH));
+            const int nfit = __popcll(__builtin_amdgcn_ballot_w64(cum_m <= PC_G_CAPM && cum_h <= PC_G_CAPH));
             const int t_last = nfit - 1;                   // last window cell; home cells are th0 .. t_last-1
+            const bool fits = t_last >= th0 + 1;
+            const int z_next = fits ? zl + t_last : z0 + 1;
+            {   // request the next window's table entries now
+                const int zl2 = z_next > 0 ? z_next - 1 : 0;
+                const int c = min(zl2 + lane, PC_NBB - 1);
+#pragma unroll
+                for (int r = 0; r < 5; r++) {
+                    a0[r] = T[tb[r] + c];
+                    a1[r] = T[tb[r] + c + 1];
+                }
+            }
 
-            if (t_last >= th0 + 1) {
+            if (fits) {
                 const uint32_t tot_m = __shfl(cum_m, t_last, 64);
                 const uint32_t tot_h = __shfl(cum_h, t_last, 64);          // row-0 points staged (home cells + cell above)
                 const uint32_t nh = __shfl(cum_h, t_last - 1, 64);         // home particles in this window
@@ -133,23 +155,43 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                 const uint32_t lo_m = __shfl_up(ex_m, 1, 64);              // start of cell t-1 in the merged array
                 const uint32_t hi_m = __shfl_down(cum_m, 1, 64);           // end of cell t+1
                 const uint32_t hi_h = __shfl_down(cum_h, 1, 64);           // end of cell t+1 in h[]
+                done = __shfl(s[0], t_last, 64);                           // start of the last window cell = next first home cell
                 if (nh != 0) {
-                    // ---- merged copy of rows 1-4: lane t copies its cell's points
-                    if (lane <= t_last) {
-                        uint32_t dst = ex_m;
+                    // ---- merged copy of rows 1-4: lane t copies its cell's points, which
+                    //      land at ex_m + v for v = 0..nm-1 in row order.  Eight loads
+                    //      are issued before the first store (one memory round trip per
+                    //      batch instead of one per point).
+                    const uint32_t mine = lane <= t_last ? nm : 0u;
+                    const uint32_t pre1 = n[1], pre2 = pre1 + n[2], pre3 = pre2 + n[3];
+                    for (uint32_t v0 = 0; __builtin_amdgcn_ballot_w64(v0 < mine) != 0; v0 += 8) {
+                        pc_f3 buf[8];
 #pragma unroll
-                        for (int r = 1; r < 5; r++) {
-                            for (uint32_t u = 0; u < n[r]; u++) {
-                                const float *p = pts + 3 * (uint64_t)(s[r] + u);
-                                L.x[dst + u] = p[0]; L.y[dst + u] = p[1]; L.z[dst + u] = p[2];
-                            }
-                            dst += n[r];
+                        for (int qq = 0; qq < 8; qq++) {
+                            const uint32_t v = v0 + qq;
+                            uint32_t src = v < pre1 ? s[1] + v : v < pre2 ? s[2] + (v - pre1)
+                                         : v < pre3 ? s[3] + (v - pre2) : s[4] + (v - pre3);
+                            if (v >= mine) src = home_lo;                  // harmless valid address
+                            buf[qq] = *reinterpret_cast<const pc_f3 *>(pts + 3 * (uint64_t)src);
+                        }
+#pragma unroll
+                        for (int qq = 0; qq < 8; qq++) {
+                            const uint32_t v = v0 + qq;
+                            if (v < mine) { L.x[ex_m + v] = buf[qq].x; L.y[ex_m + v] = buf[qq].y; L.z[ex_m + v] = buf[qq].z; }
                         }
                     }
-                    // ---- row 0: one contiguous run, all lanes
-                    for (uint32_t e = lane; e < tot_h; e += 64) {
-                        const float *p = pts + 3 * (uint64_t)(h_first + e);
-                        L.h[e] = make_float4(p[0], p[1], p[2], 0.0f);
+                    // ---- row 0: one contiguous run of at most PC_G_CAPH points, all lanes
+                    {
+                        pc_f3 buf[(PC_G_CAPH + 63) / 64];
+#pragma unroll
+                        for (int qq = 0; qq < (PC_G_CAPH + 63) / 64; qq++) {
+                            const uint32_t e = lane + 64 * qq;
+                            buf[qq] = *reinterpret_cast<const pc_f3 *>(pts + 3 * (uint64_t)(e < tot_h ? h_first + e : home_lo));
+                        }
+#pragma unroll
+                        for (int qq = 0; qq < (PC_G_CAPH + 63) / 64; qq++) {
+                            const uint32_t e = lane + 64 * qq;
+                            if (e < tot_h) L.h[e] = make_float4(buf[qq].x, buf[qq].y, buf[qq].z, 0.0f);
+                        }
                     }
                     // ---- per home particle: its merged candidate range and the end of its row-0 range
                     if (lane >= th0 && lane < t_last) {
@@ -182,8 +224,6 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                     }
                     pc_wave_lds_sync();
                 }
-                done = __shfl(s[0], t_last, 64);           // start of the last window cell = next first home cell
-                z0 = zl + t_last;
             } else {
                 // ---- home cell z0 with its neighbours does not fit: stream the
                 //      candidate ranges through LDS in pieces ---------------------
@@ -202,9 +242,18 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                     if (h0 == h1) break;                   // no home particle in this cell
                     for (uint32_t p0 = c_lo[r]; p0 < c_hi[r]; p0 += PC_G_CAPM) {
                         const uint32_t cnt = min((uint32_t)PC_G_CAPM, c_hi[r] - p0);
-                        for (uint32_t e = lane; e < cnt; e += 64) {
-                            const float *p = pts + 3 * (uint64_t)(p0 + e);
-                            L.x[e] = p[0]; L.y[e] = p[1]; L.z[e] = p[2];
+                        {
+                            pc_f3 buf[PC_G_CAPM / 64];
+#pragma unroll
+                            for (int qq = 0; qq < PC_G_CAPM / 64; qq++) {
+                                const uint32_t e = lane + 64 * qq;
+                                buf[qq] = *reinterpret_cast<const pc_f3 *>(pts + 3 * (uint64_t)(e < cnt ? p0 + e : p0));
+                            }
+#pragma unroll
+                            for (int qq = 0; qq < PC_G_CAPM / 64; qq++) {
+                                const uint32_t e = lane + 64 * qq;
+                                if (e < cnt) { L.x[e] = buf[qq].x; L.y[e] = buf[qq].y; L.z[e] = buf[qq].z; }
+                            }
                         }
                         pc_wave_lds_sync();
                         for (uint32_t i = h0 + lane; i < h1; i += 64) {
@@ -220,8 +269,8 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                     }
                 }
                 done = h1;
-                z0 += 1;
             }
+            z0 = z_next;
         }
     }
     pc_block_add_u64<PC_G_WAVES>(acc, out);

@@ -49,6 +49,19 @@ __device__ __forceinline__ void pc_wave_lds_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// Inclusive prefix sum over the 64 lanes with DPP row shifts and row broadcasts
+// (six VALU operations, no LDS traffic).
+__device__ __forceinline__ uint32_t pc_wave_incl_scan(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
 // Sum of a 32-bit value over the wave (DPP row ops + cross-row broadcast).
 __device__ __forceinline__ uint32_t pc_wave_sum(uint32_t v)
 {
