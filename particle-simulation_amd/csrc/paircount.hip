@@ -188,7 +188,7 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
     PC_LAUNCH("pc_l2_scan_x", pc_l2_scan_x, dim3(1), dim3(512), s, w.layer_count, w.layer_start, w.layer_cursor,
               w.layer_tile);
     if (n) {
-        PC_LAUNCH("pc_l3_partition_x", pc_l36_partition<0>, dim3(tiles), dim3(PC_L_TPB), s, d_xyz, n, d_sorted,
+        PC_LAUNCH("pc_l3_partition_x", pc_l36_partition<0>, dim3(tiles), dim3(PC_L_PTPB), s, d_xyz, n, d_sorted,
                   w.layer_start, w.layer_tile, w.layer_cursor);
         PC_LAUNCH("pc_l4_hist_y", pc_l4_hist_y, dim3(tiles + PC_NBB), dim3(PC_L_TPB), s, d_sorted, w.layer_start,
                   w.layer_tile, w.pencil_count, d_status);
@@ -196,7 +196,7 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
     PC_LAUNCH("pc_l5_scan_y", pc_l5_scan_y, dim3(PC_NBB), dim3(512), s, w.pencil_count, w.layer_start,
               w.pencil_start, w.pencil_cursor);
     if (n)
-        PC_LAUNCH("pc_l6_partition_y", pc_l36_partition<1>, dim3(tiles + PC_NBB), dim3(PC_L_TPB), s, d_sorted, n,
+        PC_LAUNCH("pc_l6_partition_y", pc_l36_partition<1>, dim3(tiles + PC_NBB), dim3(PC_L_PTPB), s, d_sorted, n,
                   w.tmp, w.layer_start, w.layer_tile, w.pencil_cursor);
     PC_LAUNCH("pc_l7_sort_pencils", pc_l7_sort_pencils, dim3((PC_L_NPENCILS + PC_L7_WAVES - 1) / PC_L7_WAVES),
               dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted, w.pencil_start, table, d_status);

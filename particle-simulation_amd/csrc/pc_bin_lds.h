@@ -21,8 +21,12 @@
 #define PC_L_TPB 256
 #define PC_L_PPT 16
 #define PC_L_TILE (PC_L_TPB * PC_L_PPT)        // 4096 points = 48 KB of LDS
+#define PC_L_PTPB 512                          // partition kernels: threads per tile
+#define PC_L_PPPT (PC_L_TILE / PC_L_PTPB)      // and points per thread
 #define PC_L_NPENCILS (PC_NBB * PC_NBB)        // 162409, padding pencils included
 #define PC_L_BINS 404
+
+struct pc_pt3 { float x, y, z; };              // one point of the arrays: 12 bytes, 4-byte aligned
 
 // workspace carve-up (uint32 units after the N*12-byte temp array)
 struct pc_lds_ws {
@@ -153,12 +157,12 @@ pc_l5_scan_y(const uint32_t *__restrict__ pencil_count, const uint32_t *__restri
 // LEVEL 1: tile = a chunk of one layer, bin = y cell, cursors = that layer's
 //          row of pencil_cursor.
 template <int LEVEL>
-__global__ void __launch_bounds__(PC_L_TPB)
+__global__ void __launch_bounds__(PC_L_PTPB)
 pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ dst,
                  const uint32_t *__restrict__ layer_start, const uint32_t *__restrict__ layer_tile,
                  uint32_t *__restrict__ cursor)
 {
-    __shared__ float buf[PC_L_TILE * 3];              // raw tile, then the tile sorted by bin
+    __shared__ float buf[PC_L_TILE * 3];              // the tile sorted by bin
     __shared__ uint16_t bin_of[PC_L_TILE];
     __shared__ uint32_t hist[PC_L_BINS];
     __shared__ uint32_t lstart[PC_L_BINS];
@@ -179,31 +183,28 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
         cnt = min((uint32_t)PC_L_TILE, layer_start[layer + 1] - (uint32_t)first);
         cursor += layer * PC_NBB;
     }
-    for (int b = tid; b < PC_L_BINS; b += PC_L_TPB) hist[b] = 0;
-    // raw tile -> LDS, coalesced dwords
-    const float *g = src + 3 * first;
-    for (uint32_t d = tid; d < 3 * cnt; d += PC_L_TPB) buf[d] = g[d];
+    for (int b = tid; b < PC_L_BINS; b += PC_L_PTPB) hist[b] = 0;
+    // the tile -> registers: thread t takes points t, t+TPB, ... (12-byte loads,
+    // consecutive lanes on consecutive points); all loads are issued before any use
+    const pc_pt3 *g = reinterpret_cast<const pc_pt3 *>(src) + first;
+    pc_pt3 pt[PC_L_PPPT];
+#pragma unroll
+    for (int j = 0; j < PC_L_PPPT; j++) pt[j] = g[min((uint32_t)(tid + j * PC_L_PTPB), cnt - 1)];
     __syncthreads();
 
-    // each thread: its points' bin and rank inside the bin (LDS atomic)
-    float px[PC_L_PPT], py[PC_L_PPT], pz[PC_L_PPT];
-    uint32_t tag[PC_L_PPT];                            // bin | rank << 10, or ~0 for "skip"
+    // bin and rank inside the bin (LDS atomic) of each point
+    uint32_t tag[PC_L_PPPT];                           // bin | rank << 10, or ~0 for "skip"
 #pragma unroll
-    for (int j = 0; j < PC_L_PPT; j++) {
-        const uint32_t i = tid + j * PC_L_TPB;
+    for (int j = 0; j < PC_L_PPPT; j++) {
         tag[j] = 0xFFFFFFFFu;
-        if (i < cnt) {
-            px[j] = buf[3 * i];
-            py[j] = buf[3 * i + 1];
-            pz[j] = buf[3 * i + 2];
-            const int b = pc_cell_index(LEVEL == 0 ? px[j] : py[j]);
+        if ((uint32_t)(tid + j * PC_L_PTPB) < cnt) {
+            const int b = pc_cell_index(LEVEL == 0 ? pt[j].x : pt[j].y);
             if ((unsigned)b < 400u) tag[j] = (uint32_t)b | (atomicAdd(&hist[b], 1u) << 10);
         }
     }
     __syncthreads();
 
-    // exclusive scan of the 404 bins by wave 0 (7 bins per lane), then claim
-    // global space: one atomic per non-empty bin
+    // exclusive scan of the 404 bins by wave 0 (7 bins per lane)
     if (tid < 64) {
         uint32_t c[7], s = 0;
 #pragma unroll
@@ -212,13 +213,7 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
             c[q] = b < PC_L_BINS ? hist[b] : 0u;
             s += c[q];
         }
-        uint32_t inc = s;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t v = __shfl_up(inc, off, 64);
-            if (tid >= off) inc += v;
-        }
-        uint32_t run = inc - s;
+        uint32_t run = pc_wave_incl_scan(s) - s;
 #pragma unroll
         for (int q = 0; q < 7; q++) {
             const int b = tid * 7 + q;
@@ -227,25 +222,26 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
         }
     }
     __syncthreads();
-    for (int b = tid; b < PC_L_BINS; b += PC_L_TPB) {
+    // claim global space: one atomic per non-empty bin
+    for (int b = tid; b < PC_L_BINS; b += PC_L_PTPB) {
         const uint32_t c = hist[b];
         if (c) delta[b] = atomicAdd(&cursor[b], c) - lstart[b];
     }
-    // scatter into LDS in bin order (all raw reads happened before the barrier above)
+    // the tile in bin order -> LDS
 #pragma unroll
-    for (int j = 0; j < PC_L_PPT; j++) {
+    for (int j = 0; j < PC_L_PPPT; j++) {
         if (tag[j] != 0xFFFFFFFFu) {
             const uint32_t b = tag[j] & 1023u, pos = lstart[b] + (tag[j] >> 10);
-            buf[3 * pos] = px[j];
-            buf[3 * pos + 1] = py[j];
-            buf[3 * pos + 2] = pz[j];
+            buf[3 * pos] = pt[j].x;
+            buf[3 * pos + 1] = pt[j].y;
+            buf[3 * pos + 2] = pt[j].z;
             bin_of[pos] = (uint16_t)b;
         }
     }
     __syncthreads();
     // runs -> global, coalesced dwords
     const uint32_t kept = lstart[PC_L_BINS - 1] + hist[PC_L_BINS - 1];
-    for (uint32_t d = tid; d < 3 * kept; d += PC_L_TPB) {
+    for (uint32_t d = tid; d < 3 * kept; d += PC_L_PTPB) {
         const uint32_t e = d / 3u;
         const uint32_t slot = delta[bin_of[e]] + e;
         dst[3 * (uint64_t)slot + (d - 3u * e)] = buf[d];
@@ -253,9 +249,32 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
 }
 
 // ---- L7: one wave sorts one pencil by z cell and writes its table slice --------
+// No workgroup barrier and no staging buffer: a pencil's sorted points land in a
+// window of a few KB that this one wave writes completely, so the 12-byte stores,
+// scattered inside that window, merge into full lines in the XCD's L2.
 #define PC_L7_WAVES 4
-#define PC_L7_CAP 1024                                 // points a wave stages in LDS
+#define PC_L7_CAP 1024                                 // points a wave keeps in registers
 #define PC_L7_PPL (PC_L7_CAP / 64)
+
+
+// exclusive scan of the wave's 404 bin counts in place (lane l owns bins 7l..7l+6)
+__device__ __forceinline__ void pc_l7_scan_bins(uint32_t *hist, int lane)
+{
+    uint32_t c[7], s = 0;
+#pragma unroll
+    for (int q = 0; q < 7; q++) {
+        const int b = lane * 7 + q;
+        c[q] = b < PC_L_BINS ? hist[b] : 0u;
+        s += c[q];
+    }
+    uint32_t run = pc_wave_incl_scan(s) - s;
+#pragma unroll
+    for (int q = 0; q < 7; q++) {
+        const int b = lane * 7 + q;
+        if (b < PC_L_BINS) hist[b] = run;
+        run += c[q];
+    }
+}
 
 __global__ void __launch_bounds__(PC_L7_WAVES * 64)
 pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
@@ -263,10 +282,8 @@ pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
                    int32_t *__restrict__ status)
 {
     __shared__ uint32_t hist_all[PC_L7_WAVES][PC_L_BINS];
-    __shared__ float stage_all[PC_L7_WAVES][PC_L7_CAP * 3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t *hist = hist_all[wave];
-    float *stage = stage_all[wave];
     const uint32_t pencil = blockIdx.x * PC_L7_WAVES + wave;
     if (pencil >= PC_L_NPENCILS) return;
     const uint32_t base = pencil_start[pencil], n = pencil_start[pencil + 1] - base;
@@ -278,98 +295,50 @@ pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
     }
     for (int k = lane; k < PC_L_BINS; k += 64) hist[k] = 0;
     pc_wave_lds_sync();
-    const float *g = src + 3 * (uint64_t)base;
+    const pc_pt3 *g = reinterpret_cast<const pc_pt3 *>(src) + base;
+    pc_pt3 *o = reinterpret_cast<pc_pt3 *>(dst) + base;
     bool bad = false;
 
     if (n <= PC_L7_CAP) {
-        float px[PC_L7_PPL], py[PC_L7_PPL], pz[PC_L7_PPL];
+        const int rounds = (int)((n + 63) >> 6);       // wave-uniform
+        pc_pt3 pt[PC_L7_PPL];
         uint32_t tag[PC_L7_PPL];
 #pragma unroll
+        for (int j = 0; j < PC_L7_PPL; j++)            // all loads first: one memory round trip
+            if (j < rounds) pt[j] = g[min(lane + 64u * j, n - 1)];
+#pragma unroll
         for (int j = 0; j < PC_L7_PPL; j++) {
-            const uint32_t i = lane + 64 * j;
             tag[j] = 0xFFFFFFFFu;
-            if (i < n) {
-                px[j] = g[3 * i]; py[j] = g[3 * i + 1]; pz[j] = g[3 * i + 2];
-                const int k = pc_cell_index(pz[j]);
+            if (j < rounds && lane + 64u * j < n) {
+                const int k = pc_cell_index(pt[j].z);
                 if ((unsigned)k < 400u) tag[j] = (uint32_t)k | (atomicAdd(&hist[k], 1u) << 10);
                 else bad = true;
             }
         }
-        // wave-level exclusive scan of the bins
         pc_wave_lds_sync();
-        uint32_t c[7], s = 0;
-#pragma unroll
-        for (int q = 0; q < 7; q++) {
-            const int b = lane * 7 + q;
-            c[q] = b < PC_L_BINS ? hist[b] : 0u;
-            s += c[q];
-        }
-        uint32_t inc = s;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t v = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += v;
-        }
-        uint32_t run = inc - s;
-#pragma unroll
-        for (int q = 0; q < 7; q++) {
-            const int b = lane * 7 + q;
-            if (b < PC_L_BINS) hist[b] = run;          // hist now holds the exclusive starts
-            run += c[q];
-        }
-        const uint32_t kept = __shfl(inc, 63, 64);
+        pc_l7_scan_bins(hist, lane);                   // hist now holds the exclusive starts
         pc_wave_lds_sync();
         for (int k = lane; k < PC_NBB; k += 64) slice[k] = base + hist[k];
 #pragma unroll
-        for (int j = 0; j < PC_L7_PPL; j++) {
-            if (tag[j] != 0xFFFFFFFFu) {
-                const uint32_t pos = hist[tag[j] & 1023u] + (tag[j] >> 10);
-                stage[3 * pos] = px[j]; stage[3 * pos + 1] = py[j]; stage[3 * pos + 2] = pz[j];
-            }
-        }
-        pc_wave_lds_sync();
-        float *o = dst + 3 * (uint64_t)base;
-        for (uint32_t d = lane; d < 3 * kept; d += 64) o[d] = stage[d];
+        for (int j = 0; j < PC_L7_PPL; j++)
+            if (j < rounds && tag[j] != 0xFFFFFFFFu) o[hist[tag[j] & 1023u] + (tag[j] >> 10)] = pt[j];
     } else {
-        // pencil larger than the staging buffer: histogram sweep, then a second
-        // sweep that scatters straight to global memory through LDS cursors
+        // more points than the registers hold: histogram sweep, then a second sweep
+        // that claims slots through LDS cursors
         for (uint32_t i = lane; i < n; i += 64) {
-            const int k = pc_cell_index(g[3 * (uint64_t)i + 2]);
+            const int k = pc_cell_index(g[i].z);
             if ((unsigned)k < 400u) atomicAdd(&hist[k], 1u);
             else bad = true;
         }
         pc_wave_lds_sync();
-        uint32_t c[7], s = 0;
-#pragma unroll
-        for (int q = 0; q < 7; q++) {
-            const int b = lane * 7 + q;
-            c[q] = b < PC_L_BINS ? hist[b] : 0u;
-            s += c[q];
-        }
-        uint32_t inc = s;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t v = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += v;
-        }
-        uint32_t run = inc - s;
-#pragma unroll
-        for (int q = 0; q < 7; q++) {
-            const int b = lane * 7 + q;
-            if (b < PC_L_BINS) hist[b] = run;
-            run += c[q];
-        }
+        pc_l7_scan_bins(hist, lane);
         pc_wave_lds_sync();
         for (int k = lane; k < PC_NBB; k += 64) slice[k] = base + hist[k];
         pc_wave_lds_sync();
-        float *o = dst + 3 * (uint64_t)base;
         for (uint32_t i = lane; i < n; i += 64) {
-            const float x = g[3 * (uint64_t)i], y = g[3 * (uint64_t)i + 1], z = g[3 * (uint64_t)i + 2];
-            const int k = pc_cell_index(z);
-            if ((unsigned)k < 400u) {
-                const uint32_t pos = atomicAdd(&hist[k], 1u);
-                o[3 * (uint64_t)pos] = x; o[3 * (uint64_t)pos + 1] = y; o[3 * (uint64_t)pos + 2] = z;
-            }
+            const pc_pt3 v = g[i];
+            const int k = pc_cell_index(v.z);
+            if ((unsigned)k < 400u) o[atomicAdd(&hist[k], 1u)] = v;
         }
     }
     if (bad) atomicOr(status, 1);
