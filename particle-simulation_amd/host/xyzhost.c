@@ -308,3 +308,50 @@ int64_t xyz_filter_slab(const float *in, uint64_t n, int x_lo, int x_hi, float *
     }
     return (int64_t)k;
 }
+
+/* Population of each occupied x layer (400 counters) of stream points
+   [first, first+count): what a host needs to place cost-balanced slab cuts
+   before any point is routed. */
+typedef struct { int kind; uint64_t seed; int64_t sigma; uint64_t first, count; uint64_t hist[400]; } hist_job;
+
+static void *hist_worker(void *arg)
+{
+    hist_job *j = (hist_job *)arg;
+    for (uint64_t i = j->first; i < j->first + j->count; i++) {
+        int64_t m[3];
+        xyz_point_micro(j->kind, j->seed, i, j->sigma, m);
+        int cx = xyz_cell_index(xyz_micro_to_float(m[0]));
+        if (cx >= 0 && cx < 400) j->hist[cx]++;
+    }
+    return NULL;
+}
+
+int xyz_layer_histogram(int kind, uint64_t seed, int64_t sigma_micro, uint64_t first, uint64_t count,
+                        uint64_t *hist400, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 64) nthreads = 64;
+    hist_job *jobs = (hist_job *)calloc((size_t)nthreads, sizeof(hist_job));
+    pthread_t th[64];
+    int threaded[64];
+    if (!jobs) return -3;
+    const uint64_t per = (count + (uint64_t)nthreads - 1) / (uint64_t)nthreads;
+    for (int t = 0; t < nthreads; t++) {
+        uint64_t b = (uint64_t)t * per; if (b > count) b = count;
+        uint64_t e = b + per > count ? count : b + per;
+        jobs[t].kind = kind; jobs[t].seed = seed; jobs[t].sigma = sigma_micro;
+        jobs[t].first = first + b; jobs[t].count = e - b;
+        threaded[t] = 0;
+    }
+    for (int t = 1; t < nthreads; t++) {
+        threaded[t] = pthread_create(&th[t], NULL, hist_worker, &jobs[t]) == 0;
+        if (!threaded[t]) hist_worker(&jobs[t]);
+    }
+    hist_worker(&jobs[0]);
+    for (int t = 1; t < nthreads; t++) if (threaded[t]) pthread_join(th[t], NULL);
+    memset(hist400, 0, 400 * sizeof(uint64_t));
+    for (int t = 0; t < nthreads; t++)
+        for (int l = 0; l < 400; l++) hist400[l] += jobs[t].hist[l];
+    free(jobs);
+    return 0;
+}

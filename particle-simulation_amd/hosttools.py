@@ -32,6 +32,8 @@ def lib():
         L.xyz_gen_text.restype = c.c_int64
         L.xyz_gen_text.argtypes = [c.c_int, c.c_uint64, c.c_int64, c.c_uint64, c.c_uint64, c.c_int, c.c_int,
                                    c.c_char_p, c.c_int]
+        L.xyz_layer_histogram.restype = c.c_int
+        L.xyz_layer_histogram.argtypes = [c.c_int, c.c_uint64, c.c_int64, c.c_uint64, c.c_uint64, c.c_void_p, c.c_int]
         L.xyz_filter_slab.restype = c.c_int64
         L.xyz_filter_slab.argtypes = [c.c_void_p, c.c_uint64, c.c_int, c.c_int, c.c_void_p]
         _lib = L
@@ -84,6 +86,15 @@ def generate_text(path, kind, seed, count, sigma_micro=0, first=0, x_lo=0, x_hi=
     if n < 0:
         raise RuntimeError("xyz_gen_text failed: %d" % n)
     return n
+
+
+def layer_histogram(kind, seed, count, sigma_micro=0, first=0, threads=None):
+    """Points per occupied x layer (400 entries) of a synthetic stream."""
+    hist = np.zeros(400, dtype=np.uint64)
+    rc = lib().xyz_layer_histogram(kind, seed, sigma_micro, first, count, hist.ctypes.data, threads or host_threads())
+    if rc != 0:
+        raise RuntimeError("xyz_layer_histogram failed: %d" % rc)
+    return hist
 
 
 def filter_slab(xyz, x_lo, x_hi):
