@@ -80,7 +80,51 @@ __device__ __forceinline__ uint32_t pc_g_steps(const pc_group_lds &L, uint32_t n
     return hits;    // wave-uniform (every lane holds the wave total)
 }
 
-__global__ void __launch_bounds__(PC_G_WAVES * 64)
+// Candidate-stationary form for dense data: the wave keeps 256 merged candidates
+// [p0, p0+256) in registers (four per lane, two packed pairs) and tests them
+// against every home particle h[h_lo..h_hi), whose coordinates arrive as LDS
+// broadcasts.  All candidates in [c_lo, c_hi) are valid partners, except that
+// with USE_LO a home particle only pairs with candidates at or after its own
+// meta.x & 0xFFFF (the "later slots of the same cell" rule of main.c:215-221).
+template <bool USE_LO>
+__device__ __forceinline__ uint32_t pc_g_block(const pc_group_lds &L, uint32_t c_lo, uint32_t c_hi,
+                                               uint32_t h_lo, uint32_t h_hi, int lane)
+{
+    uint32_t hits = 0;
+    c_lo = __builtin_amdgcn_readfirstlane(c_lo); c_hi = __builtin_amdgcn_readfirstlane(c_hi);
+    h_lo = __builtin_amdgcn_readfirstlane(h_lo); h_hi = __builtin_amdgcn_readfirstlane(h_hi);
+    for (uint32_t p0 = c_lo; p0 < c_hi; p0 += 256) {
+        const uint32_t p = p0 + lane;
+        const pc_v2f x01 = {L.x[p], L.x[p + 64]}, x23 = {L.x[p + 128], L.x[p + 192]};
+        const pc_v2f y01 = {L.y[p], L.y[p + 64]}, y23 = {L.y[p + 128], L.y[p + 192]};
+        const pc_v2f z01 = {L.z[p], L.z[p + 64]}, z23 = {L.z[p + 128], L.z[p + 192]};
+        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(p < c_hi), m1 = __builtin_amdgcn_ballot_w64(p + 64 < c_hi),
+                                 m2 = __builtin_amdgcn_ballot_w64(p + 128 < c_hi), m3 = __builtin_amdgcn_ballot_w64(p + 192 < c_hi);
+        for (uint32_t hp = h_lo; hp < h_hi; hp++) {
+            const float4 a = L.h[hp];
+            const pc_v2f ax = {a.x, a.x}, ay = {a.y, a.y}, az = {a.z, a.z};
+            const pc_v2f dx01 = ax - x01, dy01 = ay - y01, dz01 = az - z01;
+            const pc_v2f dx23 = ax - x23, dy23 = ay - y23, dz23 = az - z23;
+            const pc_v2f s01 = (dx01 * dx01 + dy01 * dy01) + dz01 * dz01;
+            const pc_v2f s23 = (dx23 * dx23 + dy23 * dy23) + dz23 * dz23;
+            unsigned long long b0 = __builtin_amdgcn_ballot_w64(s01.x <= 0.0025f) & m0;
+            unsigned long long b1 = __builtin_amdgcn_ballot_w64(s01.y <= 0.0025f) & m1;
+            unsigned long long b2 = __builtin_amdgcn_ballot_w64(s23.x <= 0.0025f) & m2;
+            unsigned long long b3 = __builtin_amdgcn_ballot_w64(s23.y <= 0.0025f) & m3;
+            if (USE_LO) {
+                const uint32_t lo = L.meta[hp].x & 0xFFFFu;
+                b0 &= __builtin_amdgcn_ballot_w64(p >= lo);
+                b1 &= __builtin_amdgcn_ballot_w64(p + 64 >= lo);
+                b2 &= __builtin_amdgcn_ballot_w64(p + 128 >= lo);
+                b3 &= __builtin_amdgcn_ballot_w64(p + 192 >= lo);
+            }
+            hits += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+        }
+    }
+    return hits;
+}
+
+__global__ void __launch_bounds__(PC_G_WAVES * 64, 4)   // 4 waves per SIMD: LDS admits 4 workgroups per CU
 pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T, int x_lo, int x_hi,
                    unsigned long long *__restrict__ out)
 {
@@ -209,7 +253,16 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                     else if (mean3 <= 22) hits = pc_g_steps<8>(L, nh, lane);
                     else if (mean3 <= 49) hits = pc_g_steps<16>(L, nh, lane);
                     else if (mean3 <= 106) hits = pc_g_steps<32>(L, nh, lane);
-                    else hits = pc_g_steps<64>(L, nh, lane);
+                    else {
+                        // dense window: per home cell, candidates stay in registers while the
+                        // cell's home particles stream by
+                        hits = 0;
+                        for (int t = th0; t < t_last; t++) {
+                            const uint32_t c_lo = t > 0 ? __shfl(lo_m, t, 64) : 0u, c_hi = __shfl(hi_m, t, 64);
+                            const uint32_t hb = __shfl(ex_h, t, 64), he = hb + __shfl(n[0], t, 64);
+                            hits += pc_g_block<false>(L, c_lo, c_hi, hb, he, lane);
+                        }
+                    }
                     if (lane == 0) acc += hits;
                     // ---- row 0: later points of the same cell and the cell above
                     for (uint32_t hp = lane; hp < nh; hp += 64) {
@@ -255,17 +308,28 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                                 if (e < cnt) { L.x[e] = buf[qq].x; L.y[e] = buf[qq].y; L.z[e] = buf[qq].z; }
                             }
                         }
-                        pc_wave_lds_sync();
-                        for (uint32_t i = h0 + lane; i < h1; i += 64) {
-                            const float *p = pts + 3 * (uint64_t)i;
-                            const float x = p[0], y = p[1], z = p[2];
-                            uint32_t k2 = 0;
-                            if (r == 0 && i + 1 > p0) k2 = min(i + 1 - p0, cnt);   // row 0: only slots after i
-                            uint32_t hc = 0;
-                            for (; k2 < cnt; k2++) hc += pc_hit(x, y, z, L.x[k2], L.y[k2], L.z[k2]);
-                            acc += hc;
+                        // the cell's home particles in batches: every lane works on the
+                        // piece's candidates for one home particle at a time (G = 64)
+                        for (uint32_t hb = h0; hb < h1; hb += PC_G_CAPH) {
+                            const uint32_t nhb = min((uint32_t)PC_G_CAPH, h1 - hb);
+#pragma unroll
+                            for (int qq = 0; qq < (PC_G_CAPH + 63) / 64; qq++) {
+                                const uint32_t e = lane + 64 * qq;
+                                if (e < nhb) {
+                                    const uint32_t i = hb + e;
+                                    const pc_f3 v = *reinterpret_cast<const pc_f3 *>(pts + 3 * (uint64_t)i);
+                                    uint32_t lo = 0;
+                                    if (r == 0 && i + 1 > p0) lo = min(i + 1 - p0, cnt);   // row 0: only slots after i
+                                    L.h[e] = make_float4(v.x, v.y, v.z, 0.0f);
+                                    L.meta[e] = make_uint2(lo | (cnt << 16), 0u);
+                                }
+                            }
+                            pc_wave_lds_sync();
+                            const uint32_t hits = r == 0 ? pc_g_block<true>(L, 0, cnt, 0, nhb, lane)
+                                                         : pc_g_block<false>(L, 0, cnt, 0, nhb, lane);
+                            if (lane == 0) acc += hits;
+                            pc_wave_lds_sync();
                         }
-                        pc_wave_lds_sync();
                     }
                 }
                 done = h1;
