@@ -151,14 +151,18 @@ static inline uint32_t scan_tiles(uint64_t m) { return (uint32_t)((m + PC_SCAN_T
 static inline int grid_for(uint64_t n, int tpb, int cap);
 
 // uint32 counters of the LDS variant, after its N*12-byte temp array
-static const size_t LDS_WS_COUNTERS = PC_L_BINS + (PC_L_NPENCILS + 3) + 3 * PC_L_BINS + 2 * (PC_L_NPENCILS + 1);
+static inline size_t lds_ws_counters(uint64_t n)
+{
+    return (size_t)PC_L_NREP * PC_L_BINS + (size_t)PC_L_NREP * PC_L_PSTRIDE + PC_L_BINS + (size_t)PC_L_NREP * PC_L_BINS + PC_L_BINS +
+           ((n + PC_L_TILE - 1) / PC_L_TILE + PC_L_BINS) + (PC_L_NPENCILS + 1) + (size_t)PC_L_NREP * PC_L_PSTRIDE;
+}
 
 extern "C" size_t pc_workspace_bytes(uint64_t n)
 {
     size_t keys = align_up((size_t)n * 4 + 4, 256);
     size_t sums = align_up((size_t)scan_tiles(PC_NCELLS + 2) * 4, 256);
     size_t v0 = keys + sums + 256;
-    size_t v1 = align_up((size_t)n * 12 + 16, 256) + align_up(LDS_WS_COUNTERS * 4, 256) + 256;
+    size_t v1 = align_up((size_t)n * 12 + 16, 256) + align_up(lds_ws_counters(n) * 4, 256) + 256;
     return v0 > v1 ? v0 : v1;
 }
 
@@ -167,11 +171,12 @@ static pc_lds_ws carve_lds_ws(void *ws, uint64_t n)
     pc_lds_ws w;
     w.tmp = (float *)ws;
     uint32_t *u = (uint32_t *)((char *)ws + align_up((size_t)n * 12 + 16, 256));
-    w.layer_count = u;            u += PC_L_BINS;
-    w.pencil_count = u;           u += PC_L_NPENCILS + 3;
+    w.layer_count = u;            u += PC_L_NREP * PC_L_BINS;
+    w.pencil_count = u;           u += PC_L_NREP * PC_L_PSTRIDE;
     w.layer_start = u;            u += PC_L_BINS;
-    w.layer_cursor = u;           u += PC_L_BINS;
+    w.layer_cursor = u;           u += PC_L_NREP * PC_L_BINS;
     w.layer_tile = u;             u += PC_L_BINS;
+    w.tile_layer = u;             u += (n + PC_L_TILE - 1) / PC_L_TILE + PC_L_BINS;
     w.pencil_start = u;           u += PC_L_NPENCILS + 1;
     w.pencil_cursor = u;
     return w;
@@ -181,23 +186,23 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
                    int32_t *d_status, hipStream_t s)
 {
     pc_lds_ws w = carve_lds_ws(ws, n);
-    PC_HIP(hipMemsetAsync(w.layer_count, 0, (PC_L_BINS + PC_L_NPENCILS + 3) * sizeof(uint32_t), s));
+    PC_HIP(hipMemsetAsync(w.layer_count, 0, (PC_L_NREP * PC_L_BINS + PC_L_NREP * PC_L_PSTRIDE) * sizeof(uint32_t), s));
     const int tiles = (int)((n + PC_L_TILE - 1) / PC_L_TILE);
-    if (n) PC_LAUNCH("pc_l1_hist_x", pc_l1_hist_x, dim3(grid_for(n, PC_L_TPB * 8, 2048)), dim3(PC_L_TPB), s,
+    if (n) PC_LAUNCH("pc_l1_hist_x", pc_l1_hist_x, dim3(grid_for(n, PC_L_TILE, 2048)), dim3(PC_L_TPB), s,
                      d_xyz, n, w.layer_count, d_status);
     PC_LAUNCH("pc_l2_scan_x", pc_l2_scan_x, dim3(1), dim3(512), s, w.layer_count, w.layer_start, w.layer_cursor,
-              w.layer_tile);
+              w.layer_tile, w.tile_layer);
     if (n) {
         PC_LAUNCH("pc_l3_partition_x", pc_l36_partition<0>, dim3(tiles), dim3(PC_L_PTPB), s, d_xyz, n, d_sorted,
-                  w.layer_start, w.layer_tile, w.layer_cursor);
+                  w.layer_start, w.layer_tile, w.tile_layer, w.layer_cursor);
         PC_LAUNCH("pc_l4_hist_y", pc_l4_hist_y, dim3(tiles + PC_NBB), dim3(PC_L_TPB), s, d_sorted, w.layer_start,
-                  w.layer_tile, w.pencil_count, d_status);
+                  w.layer_tile, w.tile_layer, w.pencil_count, d_status);
     }
     PC_LAUNCH("pc_l5_scan_y", pc_l5_scan_y, dim3(PC_NBB), dim3(512), s, w.pencil_count, w.layer_start,
               w.pencil_start, w.pencil_cursor);
     if (n)
         PC_LAUNCH("pc_l6_partition_y", pc_l36_partition<1>, dim3(tiles + PC_NBB), dim3(PC_L_PTPB), s, d_sorted, n,
-                  w.tmp, w.layer_start, w.layer_tile, w.pencil_cursor);
+                  w.tmp, w.layer_start, w.layer_tile, w.tile_layer, w.pencil_cursor);
     PC_LAUNCH("pc_l7_sort_pencils", pc_l7_sort_pencils, dim3((PC_L_NPENCILS + PC_L7_WAVES - 1) / PC_L7_WAVES),
               dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted, w.pencil_start, table, d_status);
     PC_HIP(hipGetLastError());

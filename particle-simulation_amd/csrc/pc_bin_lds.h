@@ -28,19 +28,30 @@
 
 struct pc_pt3 { float x, y, z; };              // one point of the arrays: 12 bytes, 4-byte aligned
 
+#define PC_L_NREP 8                            // levels X and Y keep one cursor set per XCD group (tile % 8)
+#define PC_L_PSTRIDE (PC_L_NPENCILS + 7)        // pencil counters per replica (padded)
+
 // workspace carve-up (uint32 units after the N*12-byte temp array)
 struct pc_lds_ws {
     float *tmp;               // N*3 floats
-    uint32_t *layer_count;    // [404]   zeroed each call   } contiguous, one memset
-    uint32_t *pencil_count;   // [162409+3] zeroed each call }
+    uint32_t *layer_count;    // [NREP][404] zeroed each call   } contiguous, one memset
+    uint32_t *pencil_count;   // [NREP][PSTRIDE] zeroed each call }
     uint32_t *layer_start;    // [404]
-    uint32_t *layer_cursor;   // [404]
-    uint32_t *layer_tile;     // [404]  prefix of tiles per layer (levels Y)
+    uint32_t *layer_cursor;   // [NREP][404]
+    uint32_t *layer_tile;     // [404]  prefix of tiles per layer (level Y)
+    uint32_t *tile_layer;     // [tiles+404] layer of each level-Y tile
     uint32_t *pencil_start;   // [162409+1]
-    uint32_t *pencil_cursor;  // [162409+1]
+    uint32_t *pencil_cursor;  // [NREP][PSTRIDE]
 };
 
 // ---- L1: histogram of x layers ---------------------------------------------
+// Tile t of the input (4096 points) belongs to replica t % NREP.  A layer's
+// region of the level-X output is split into NREP sub-regions, one per replica:
+// the partition kernel runs tile t as workgroup t, workgroups t and t+8 share an
+// XCD (round-robin dispatch), so each sub-region is written by one XCD only and
+// its partial lines complete in that XCD's L2; it also spreads the cursor
+// atomics over NREP words per layer.  The grid is a multiple of NREP, so every
+// tile a workgroup visits has the same replica.
 __global__ void __launch_bounds__(PC_L_TPB)
 pc_l1_hist_x(const float *__restrict__ xyz, uint64_t n, uint32_t *__restrict__ layer_count,
              int32_t *__restrict__ status)
@@ -49,28 +60,47 @@ pc_l1_hist_x(const float *__restrict__ xyz, uint64_t n, uint32_t *__restrict__ l
     for (int b = threadIdx.x; b < PC_L_BINS; b += PC_L_TPB) h[b] = 0;
     __syncthreads();
     bool bad = false;
-    const uint64_t stride = (uint64_t)gridDim.x * PC_L_TPB;
-    for (uint64_t p = (uint64_t)blockIdx.x * PC_L_TPB + threadIdx.x; p < n; p += stride) {
-        const int i = pc_cell_index(xyz[3 * p]);
-        if ((unsigned)i >= 400u) { bad = true; continue; }
-        atomicAdd(&h[i], 1u);
+    const uint64_t ntiles = (n + PC_L_TILE - 1) / PC_L_TILE;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint64_t first = t * PC_L_TILE;
+        const uint32_t cnt = (uint32_t)min((uint64_t)PC_L_TILE, n - first);
+        float xs[PC_L_PPT];
+#pragma unroll
+        for (int j = 0; j < PC_L_PPT; j++)
+            xs[j] = xyz[3 * (first + min((uint32_t)(threadIdx.x + j * PC_L_TPB), cnt - 1))];
+#pragma unroll
+        for (int j = 0; j < PC_L_PPT; j++) {
+            if ((uint32_t)(threadIdx.x + j * PC_L_TPB) < cnt) {
+                const int i = pc_cell_index(xs[j]);
+                if ((unsigned)i < 400u) atomicAdd(&h[i], 1u);
+                else bad = true;
+            }
+        }
     }
     __syncthreads();
+    uint32_t *mine = layer_count + (blockIdx.x % PC_L_NREP) * PC_L_BINS;
     for (int b = threadIdx.x; b < 400; b += PC_L_TPB)
-        if (h[b]) atomicAdd(&layer_count[b], h[b]);
+        if (h[b]) atomicAdd(&mine[b], h[b]);
     if (bad) atomicOr(status, 1);
 }
 
 // ---- L2: scan of the 403 layer counts (one workgroup) ------------------------
 __global__ void __launch_bounds__(512)
 pc_l2_scan_x(const uint32_t *__restrict__ layer_count, uint32_t *__restrict__ layer_start,
-             uint32_t *__restrict__ layer_cursor, uint32_t *__restrict__ layer_tile)
+             uint32_t *__restrict__ layer_cursor, uint32_t *__restrict__ layer_tile,
+             uint32_t *__restrict__ tile_layer)
 {
     __shared__ uint32_t a[512], t[512];
     const int i = threadIdx.x;
-    const uint32_t c = i < PC_NBB ? layer_count[i] : 0u;
+    uint32_t rep[PC_L_NREP], c = 0;
+#pragma unroll
+    for (int g = 0; g < PC_L_NREP; g++) {
+        rep[g] = i < PC_NBB ? layer_count[g * PC_L_BINS + i] : 0u;
+        c += rep[g];
+    }
+    const uint32_t my_tiles = (c + PC_L_TILE - 1) / PC_L_TILE;
     a[i] = c;
-    t[i] = (c + PC_L_TILE - 1) / PC_L_TILE;
+    t[i] = my_tiles;
     __syncthreads();
     for (int off = 1; off < 512; off <<= 1) {          // Hillis-Steele, inclusive
         uint32_t va = i >= off ? a[i - off] : 0u, vt = i >= off ? t[i - off] : 0u;
@@ -80,48 +110,50 @@ pc_l2_scan_x(const uint32_t *__restrict__ layer_count, uint32_t *__restrict__ la
         __syncthreads();
     }
     if (i < PC_L_BINS) {
-        const uint32_t ex = a[i] - c;
-        layer_start[i] = ex;
-        layer_cursor[i] = ex;
-        layer_tile[i] = t[i] - (c + PC_L_TILE - 1) / PC_L_TILE;
+        uint32_t run = a[i] - c;                       // first slot of layer i
+        layer_start[i] = run;
+#pragma unroll
+        for (int g = 0; g < PC_L_NREP; g++) {          // replica sub-regions, in replica order
+            layer_cursor[g * PC_L_BINS + i] = run;
+            run += rep[g];
+        }
+        const uint32_t tile0 = t[i] - my_tiles;
+        layer_tile[i] = tile0;
+        for (uint32_t k = 0; k < my_tiles; k++) tile_layer[tile0 + k] = (uint32_t)i;
     }
-}
-
-// Which layer does tile `b` of levels Y belong to?  layer_tile is the exclusive
-// prefix of tiles per layer; entry 403 holds the total.
-__device__ __forceinline__ int pc_find_layer(const uint32_t *__restrict__ layer_tile, uint32_t b)
-{
-    int lo = 0, hi = PC_NBB;                           // invariant: layer_tile[lo] <= b < layer_tile[hi]
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (layer_tile[mid] <= b) lo = mid; else hi = mid;
-    }
-    return lo;
 }
 
 // ---- L4: histogram of pencils inside each layer ------------------------------
+// Level-Y tile b is chunk (b - layer_tile[layer]) of layer tile_layer[b].
 __global__ void __launch_bounds__(PC_L_TPB)
 pc_l4_hist_y(const float *__restrict__ pts, const uint32_t *__restrict__ layer_start,
-             const uint32_t *__restrict__ layer_tile, uint32_t *__restrict__ pencil_count,
-             int32_t *__restrict__ status)
+             const uint32_t *__restrict__ layer_tile, const uint32_t *__restrict__ tile_layer,
+             uint32_t *__restrict__ pencil_count, int32_t *__restrict__ status)
 {
     __shared__ uint32_t h[PC_L_BINS];
     if (blockIdx.x >= layer_tile[PC_NBB]) return;
-    const int layer = pc_find_layer(layer_tile, blockIdx.x);
+    const int layer = (int)tile_layer[blockIdx.x];
     const uint32_t chunk = blockIdx.x - layer_tile[layer];
     const uint32_t first = layer_start[layer] + chunk * PC_L_TILE;
-    const uint32_t stop = min(first + PC_L_TILE, layer_start[layer + 1]);
+    const uint32_t cnt = min((uint32_t)PC_L_TILE, layer_start[layer + 1] - first);
     for (int b = threadIdx.x; b < PC_L_BINS; b += PC_L_TPB) h[b] = 0;
+    float ys[PC_L_PPT];
+#pragma unroll
+    for (int j = 0; j < PC_L_PPT; j++)
+        ys[j] = pts[3 * ((uint64_t)first + min((uint32_t)(threadIdx.x + j * PC_L_TPB), cnt - 1)) + 1];
     __syncthreads();
     bool bad = false;
-    for (uint32_t p = first + threadIdx.x; p < stop; p += PC_L_TPB) {
-        const int j = pc_cell_index(pts[3 * (uint64_t)p + 1]);
-        if ((unsigned)j >= 400u) { bad = true; continue; }
-        atomicAdd(&h[j], 1u);
+#pragma unroll
+    for (int j = 0; j < PC_L_PPT; j++) {
+        if ((uint32_t)(threadIdx.x + j * PC_L_TPB) < cnt) {
+            const int jy = pc_cell_index(ys[j]);
+            if ((unsigned)jy < 400u) atomicAdd(&h[jy], 1u);
+            else bad = true;
+        }
     }
     __syncthreads();
     for (int b = threadIdx.x; b < 400; b += PC_L_TPB)
-        if (h[b]) atomicAdd(&pencil_count[layer * PC_NBB + b], h[b]);
+        if (h[b]) atomicAdd(&pencil_count[(blockIdx.x % PC_L_NREP) * PC_L_PSTRIDE + layer * PC_NBB + b], h[b]);
     if (bad) atomicOr(status, 1);
 }
 
@@ -134,7 +166,12 @@ pc_l5_scan_y(const uint32_t *__restrict__ pencil_count, const uint32_t *__restri
 {
     __shared__ uint32_t a[512];
     const int j = threadIdx.x, layer = blockIdx.x;
-    const uint32_t c = j < PC_NBB ? pencil_count[layer * PC_NBB + j] : 0u;
+    uint32_t rep[PC_L_NREP], c = 0;
+#pragma unroll
+    for (int g = 0; g < PC_L_NREP; g++) {
+        rep[g] = j < PC_NBB ? pencil_count[g * PC_L_PSTRIDE + layer * PC_NBB + j] : 0u;
+        c += rep[g];
+    }
     a[j] = c;
     __syncthreads();
     for (int off = 1; off < 512; off <<= 1) {
@@ -146,7 +183,12 @@ pc_l5_scan_y(const uint32_t *__restrict__ pencil_count, const uint32_t *__restri
     const uint32_t ex = layer_start[layer] + a[j] - c;
     if (j < PC_NBB) {
         pencil_start[layer * PC_NBB + j] = ex;
-        pencil_cursor[layer * PC_NBB + j] = ex;
+        uint32_t run = ex;
+#pragma unroll
+        for (int g = 0; g < PC_L_NREP; g++) {          // replica sub-regions of the pencil, as in level X
+            pencil_cursor[g * PC_L_PSTRIDE + layer * PC_NBB + j] = run;
+            run += rep[g];
+        }
     }
     if (layer == PC_NBB - 1 && j == PC_NBB) pencil_start[PC_L_NPENCILS] = ex;   // total
 }
@@ -160,7 +202,7 @@ template <int LEVEL>
 __global__ void __launch_bounds__(PC_L_PTPB)
 pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ dst,
                  const uint32_t *__restrict__ layer_start, const uint32_t *__restrict__ layer_tile,
-                 uint32_t *__restrict__ cursor)
+                 const uint32_t *__restrict__ tile_layer, uint32_t *__restrict__ cursor)
 {
     __shared__ float buf[PC_L_TILE * 3];              // the tile sorted by bin
     __shared__ uint16_t bin_of[PC_L_TILE];
@@ -175,13 +217,14 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
         first = (uint64_t)blockIdx.x * PC_L_TILE;
         if (first >= n) return;
         cnt = (uint32_t)min((uint64_t)PC_L_TILE, n - first);
+        cursor += (blockIdx.x % PC_L_NREP) * PC_L_BINS;       // this tile's replica (see L1)
     } else {
         if (blockIdx.x >= layer_tile[PC_NBB]) return;
-        const int layer = pc_find_layer(layer_tile, blockIdx.x);
+        const int layer = (int)tile_layer[blockIdx.x];
         const uint32_t chunk = blockIdx.x - layer_tile[layer];
         first = (uint64_t)layer_start[layer] + (uint64_t)chunk * PC_L_TILE;
         cnt = min((uint32_t)PC_L_TILE, layer_start[layer + 1] - (uint32_t)first);
-        cursor += layer * PC_NBB;
+        cursor += (blockIdx.x % PC_L_NREP) * PC_L_PSTRIDE + layer * PC_NBB;
     }
     for (int b = tid; b < PC_L_BINS; b += PC_L_PTPB) hist[b] = 0;
     // the tile -> registers: thread t takes points t, t+TPB, ... (12-byte loads,

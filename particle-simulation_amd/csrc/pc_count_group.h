@@ -25,7 +25,7 @@
 #pragma once
 #include "pc_device.h"
 
-#define PC_G_WAVES 4
+#define PC_G_WAVES 1
 #define PC_G_CAPM 448                   // merged candidates (rows 1-4) per window
 #define PC_G_CAPH 160                   // row-0 points per window
 #define PC_G_BAND (PC_NLAYERS / 8)
