@@ -262,6 +262,34 @@ extern "C" int pc_bin_device(const float *d_xyz, uint64_t n, float *d_sorted_xyz
     return PC_OK;
 }
 
+// Work counters of the persistent pair-test kernel: a small array in the code
+// object (each device holds its own copy), zeroed on the launch stream before
+// every launch.  Two pair-test launches that overlap on one device would share
+// it; the library's own entry points never overlap launches on a device.
+static __device__ __align__(256) unsigned int pc_count_queue_words[8 * PC_G_QUEUE_STRIDE];
+static unsigned int *g_queue_ptr[64];
+static pthread_mutex_t g_queue_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static int count_queue(unsigned int **out)
+{
+    int dev = 0;
+    PC_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return pc_fail(PC_ERR_ARG, "device ordinal %d not supported", dev);
+    pthread_mutex_lock(&g_queue_lock);
+    unsigned int *p = g_queue_ptr[dev];
+    if (!p) {
+        hipError_t e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(pc_count_queue_words));
+        if (e != hipSuccess) {
+            pthread_mutex_unlock(&g_queue_lock);
+            return pc_fail(PC_ERR_HIP, "hipGetSymbolAddress(work counters): %s", hipGetErrorString(e));
+        }
+        g_queue_ptr[dev] = p;
+    }
+    pthread_mutex_unlock(&g_queue_lock);
+    *out = p;
+    return PC_OK;
+}
+
 static int check_slab(const char *who, int x_lo, int x_hi)
 {
     if (x_lo < 0 || x_hi > PC_NLAYERS || x_lo > x_hi)
@@ -284,9 +312,16 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
         PC_LAUNCH("pc_c0_count_global", pc_c0_count_global, dim3(grid_for(n, 256, 1 << 20)), dim3(256), (hipStream_t)stream, d_sorted_xyz, d_cell_start, c_lo, c_hi,
                            (unsigned long long *)d_npairs);
     } else if (g_variant_count == 3) {
-        const int grid = 8 * (x_hi - x_lo) * PC_G_WG_PER_BAND;
+        // persistent: 16 waves per CU (VGPR-limited residency), never more waves than pencils;
+        // the eight work counters are zeroed on the stream ahead of the launch
+        unsigned int *queue = nullptr;
+        int rc2 = count_queue(&queue);
+        if (rc2) return rc2;
+        PC_HIP(hipMemsetAsync(queue, 0, 8 * PC_G_QUEUE_STRIDE * sizeof(unsigned int), (hipStream_t)stream));
+        const int want = 256 * 16 / PC_G_WAVES, most = ((x_hi - x_lo) * PC_NLAYERS + PC_G_WAVES - 1) / PC_G_WAVES;
+        const int grid = ((want < most ? want : most) + 7) / 8 * 8;
         PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
-                  d_sorted_xyz, d_cell_start, x_lo, x_hi, (unsigned long long *)d_npairs);
+                  d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, (unsigned long long *)d_npairs);
     } else if (g_variant_count == 2) {
         const int grid = 8 * (x_hi - x_lo) * PC_W_WG_PER_BAND;
         PC_LAUNCH("pc_c2_count_waves", pc_c2_count_waves, dim3(grid), dim3(PC_W_WAVES * 64), (hipStream_t)stream,

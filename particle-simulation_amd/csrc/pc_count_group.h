@@ -29,6 +29,7 @@
 #define PC_G_CAPM 448                   // merged candidates (rows 1-4) per window
 #define PC_G_CAPH 160                   // row-0 points per window
 #define PC_G_BAND (PC_NLAYERS / 8)
+#define PC_G_QUEUE_STRIDE 32             // one work counter per XCD group, each on its own 128-byte line
 #define PC_G_WG_PER_BAND ((PC_G_BAND + PC_G_WAVES - 1) / PC_G_WAVES)
 
 typedef float pc_v2f __attribute__((ext_vector_type(2)));
@@ -126,18 +127,31 @@ __device__ __forceinline__ uint32_t pc_g_block(const pc_group_lds &L, uint32_t c
 
 __global__ void __launch_bounds__(PC_G_WAVES * 64, 4)   // 4 waves per SIMD: LDS admits 4 workgroups per CU
 pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T, int x_lo, int x_hi,
-                   unsigned long long *__restrict__ out)
+                   unsigned int *__restrict__ queue, unsigned long long *__restrict__ out)
 {
     __shared__ pc_group_lds lds_all[PC_G_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     pc_group_lds &L = lds_all[wave];
     unsigned long long acc = 0;          // per-lane partial (lane 0 also carries the wave-uniform hit counts)
 
-    const int g = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int layer = x_lo + q / PC_G_WG_PER_BAND;
-    const int jb = (q % PC_G_WG_PER_BAND) * PC_G_WAVES + wave;
-    const int j = g * PC_G_BAND + jb;
-    if (layer < x_hi && jb < PC_G_BAND) {
+    // Persistent waves with a work queue per XCD group.  Workgroups with equal
+    // blockIdx%8 share an XCD; that group owns the band of 50 pencils
+    // y = g*50 .. g*50+49 of every layer and its waves draw the band's pencils
+    // (layer-major) from the group's counter, so neighbouring pencils are in flight
+    // together and a wave that finishes a light pencil simply draws the next one.
+    // The next index is drawn before the current pencil is processed (its latency
+    // is hidden); every wave leaves the loop when its draw passes the end.
+    const int g = blockIdx.x & 7;
+    const int band_pencils = (x_hi - x_lo) * PC_G_BAND;
+    unsigned int *q = queue + g * PC_G_QUEUE_STRIDE;
+    int m = 0;
+    if (lane == 0) m = (int)atomicAdd(q, 1u);
+    m = __builtin_amdgcn_readfirstlane(m);
+    while (m < band_pencils) {
+        int m_next = 0;
+        if (lane == 0) m_next = (int)atomicAdd(q, 1u);
+        const int layer = x_lo + m / PC_G_BAND;
+        const int j = g * PC_G_BAND + m % PC_G_BAND;
         // table bases of the five rows; invalid rows (outside the occupied grid) are empty
         const int ri[5] = {layer, layer, layer + 1, layer + 1, layer + 1};
         const int rj[5] = {j, j + 1, j - 1, j, j + 1};
@@ -336,6 +350,7 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
             }
             z0 = z_next;
         }
+        m = __builtin_amdgcn_readfirstlane(m_next);
     }
     pc_block_add_u64<PC_G_WAVES>(acc, out);
 }
