@@ -27,17 +27,24 @@
 
 #define PC_G_WAVES 1
 #define PC_G_CAPM 448                   // merged candidates (rows 1-4) per window
-#define PC_G_CAPH 160                   // row-0 points per window
+#define PC_G_CAPH 144                   // row-0 points per window
 #define PC_G_BAND (PC_NLAYERS / 8)
 #define PC_G_QUEUE_STRIDE 32             // one work counter per XCD group, each on its own 128-byte line
 #define PC_G_WG_PER_BAND ((PC_G_BAND + PC_G_WAVES - 1) / PC_G_WAVES)
 
 typedef float pc_v2f __attribute__((ext_vector_type(2)));
 struct pc_f3 { float x, y, z; };          // one point as stored in the sorted array (12 bytes, 4-byte aligned)
+struct pc_h6 { pc_v2f x, y, z; };         // a home particle as {x,x},{y,y},{z,z}: ready-made operands for packed math
+__device__ __forceinline__ pc_h6 pc_make_h6(float x, float y, float z)
+{
+    pc_h6 h;
+    h.x = pc_v2f{x, x}; h.y = pc_v2f{y, y}; h.z = pc_v2f{z, z};
+    return h;
+}
 
 struct pc_group_lds {
     float x[PC_G_CAPM], y[PC_G_CAPM], z[PC_G_CAPM];   // merged rows 1-4 (reads may run past the end into h[])
-    float4 h[PC_G_CAPH];                               // row 0: home cells and the cell above
+    pc_h6 h[PC_G_CAPH];                                // row 0: home cells and the cell above, coordinates duplicated
     uint2 meta[PC_G_CAPH];                             // per home particle: .x = lo | hi<<16 (merged range), .y = end of its row-0 range
 };
 
@@ -53,11 +60,12 @@ __device__ __forceinline__ uint32_t pc_g_steps(const pc_group_lds &L, uint32_t n
     for (uint32_t base = 0; base < nh; base += 64 / G) {
         const uint32_t hp = min(base + grp, nh - 1);
         const uint2 m = L.meta[hp];
-        const float4 a = L.h[hp];
+        const pc_h6 a = L.h[hp];
+        const bool live = base + grp < nh;
         uint32_t p = (m.x & 0xFFFFu) + j;
         // candidates this lane still has to test, counted in units of one: slot c is live iff rem > c*G
-        int rem = base + grp < nh ? (int)(m.x >> 16) - (int)p : 0;
-        const pc_v2f ax = {a.x, a.x}, ay = {a.y, a.y}, az = {a.z, a.z};
+        int rem = live ? (int)(m.x >> 16) - (int)p : 0;
+        const pc_v2f ax = a.x, ay = a.y, az = a.z;
         for (;;) {
             const pc_v2f x01 = {L.x[p], L.x[p + G]}, x23 = {L.x[p + 2 * G], L.x[p + 3 * G]};
             const pc_v2f y01 = {L.y[p], L.y[p + G]}, y23 = {L.y[p + 2 * G], L.y[p + 3 * G]};
@@ -76,6 +84,19 @@ __device__ __forceinline__ uint32_t pc_g_steps(const pc_group_lds &L, uint32_t n
             rem -= 4 * G;
             p += 4 * G;
             if (__builtin_amdgcn_ballot_w64(rem > 0) == 0) break;
+        }
+        // same pencil: later points of the home cell and the cell above are h[hp+1 .. m.y),
+        // one candidate per lane of the group (main.c:215-221 and offset (0,0,1))
+        uint32_t p0 = hp + 1 + j;
+        int rem0 = live ? (int)m.y - (int)p0 : 0;
+        for (;;) {
+            const pc_h6 &v = L.h[min(p0, (uint32_t)PC_G_CAPH - 1)];
+            const float dx = ax.x - v.x.x, dy = ay.x - v.y.x, dz = az.x - v.z.x;
+            const float sq = (dx * dx + dy * dy) + dz * dz;
+            hits += __popcll(__builtin_amdgcn_ballot_w64(sq <= 0.0025f) & __builtin_amdgcn_ballot_w64(rem0 > 0));
+            rem0 -= G;
+            p0 += G;
+            if (__builtin_amdgcn_ballot_w64(rem0 > 0) == 0) break;
         }
     }
     return hits;    // wave-uniform (every lane holds the wave total)
@@ -102,8 +123,8 @@ __device__ __forceinline__ uint32_t pc_g_block(const pc_group_lds &L, uint32_t c
         const unsigned long long m0 = __builtin_amdgcn_ballot_w64(p < c_hi), m1 = __builtin_amdgcn_ballot_w64(p + 64 < c_hi),
                                  m2 = __builtin_amdgcn_ballot_w64(p + 128 < c_hi), m3 = __builtin_amdgcn_ballot_w64(p + 192 < c_hi);
         for (uint32_t hp = h_lo; hp < h_hi; hp++) {
-            const float4 a = L.h[hp];
-            const pc_v2f ax = {a.x, a.x}, ay = {a.y, a.y}, az = {a.z, a.z};
+            const pc_h6 a = L.h[hp];
+            const pc_v2f ax = a.x, ay = a.y, az = a.z;
             const pc_v2f dx01 = ax - x01, dy01 = ay - y01, dz01 = az - z01;
             const pc_v2f dx23 = ax - x23, dy23 = ay - y23, dz23 = az - z23;
             const pc_v2f s01 = (dx01 * dx01 + dy01 * dy01) + dz01 * dz01;
@@ -248,7 +269,7 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
 #pragma unroll
                         for (int qq = 0; qq < (PC_G_CAPH + 63) / 64; qq++) {
                             const uint32_t e = lane + 64 * qq;
-                            if (e < tot_h) L.h[e] = make_float4(buf[qq].x, buf[qq].y, buf[qq].z, 0.0f);
+                            if (e < tot_h) L.h[e] = pc_make_h6(buf[qq].x, buf[qq].y, buf[qq].z);
                         }
                     }
                     // ---- per home particle: its merged candidate range and the end of its row-0 range
@@ -276,19 +297,19 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                             const uint32_t hb = __shfl(ex_h, t, 64), he = hb + __shfl(n[0], t, 64);
                             hits += pc_g_block<false>(L, c_lo, c_hi, hb, he, lane);
                         }
+                        // same pencil (the steps above count these themselves): lane per home particle
+                        for (uint32_t hp = lane; hp < nh; hp += 64) {
+                            const pc_h6 &me = L.h[hp];
+                            const uint32_t end = L.meta[hp].y;
+                            uint32_t cnt = 0;
+                            for (uint32_t k2 = hp + 1; k2 < end; k2++) {
+                                const pc_h6 &v = L.h[k2];
+                                cnt += pc_hit(me.x.x, me.y.x, me.z.x, v.x.x, v.y.x, v.z.x);
+                            }
+                            acc += cnt;
+                        }
                     }
                     if (lane == 0) acc += hits;
-                    // ---- row 0: later points of the same cell and the cell above
-                    for (uint32_t hp = lane; hp < nh; hp += 64) {
-                        const float4 me = L.h[hp];
-                        const uint32_t end = L.meta[hp].y;
-                        uint32_t cnt = 0;
-                        for (uint32_t k2 = hp + 1; k2 < end; k2++) {
-                            const float4 v = L.h[k2];
-                            cnt += pc_hit(me.x, me.y, me.z, v.x, v.y, v.z);
-                        }
-                        acc += cnt;
-                    }
                     pc_wave_lds_sync();
                 }
             } else {
@@ -334,7 +355,7 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                                     const pc_f3 v = *reinterpret_cast<const pc_f3 *>(pts + 3 * (uint64_t)i);
                                     uint32_t lo = 0;
                                     if (r == 0 && i + 1 > p0) lo = min(i + 1 - p0, cnt);   // row 0: only slots after i
-                                    L.h[e] = make_float4(v.x, v.y, v.z, 0.0f);
+                                    L.h[e] = pc_make_h6(v.x, v.y, v.z);
                                     L.meta[e] = make_uint2(lo | (cnt << 16), 0u);
                                 }
                             }
