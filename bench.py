@@ -254,7 +254,21 @@ def cpu_baseline(psa, ht, st, torch, kind, seed, total_points, sigma, device):
                 return {"error": "reference binary failed rc=%d: %s" % (r.returncode, r.stderr[-200:])}
             phases = {m.group(1): int(m.group(2)) / 1e6 for m in re.finditer(r"(\w+):\s+(\d+) us", r.stdout)}
             count = int([ln for ln in r.stdout.splitlines() if ln.strip().isdigit()][-1])
-            return {"value": tests / phases["count"], "unit": "pairs-tested/s", "cores": cores, "kind": "reference",
+            # the same file through the product's C host program (tokenize on the host, bin+count on the GPU)
+            e2e = None
+            main_bin = ht.MAIN_PATH
+            if os.path.exists(main_bin):
+                t1 = time.time()
+                g = subprocess.run([main_bin, "-f", path, "-p", str(cores)], capture_output=True, text=True,
+                                   timeout=900, env=dict(os.environ, PAIRCOUNT_TIMER="1"))
+                gwall = time.time() - t1
+                if g.returncode == 0:
+                    gph = {m.group(1): float(m.group(2)) / 1e6 for m in re.finditer(r"(\w[\w()]*):\s+(\d+) us", g.stderr)}
+                    e2e = {"file_bytes": os.path.getsize(path), "gpu_host_program_wall_s": gwall, "gpu_phases_s": gph,
+                           "gpu_count": int(g.stdout.strip()), "reference_wall_s": wall,
+                           "note": "process start to count printed, same file; the GPU program's wall time includes HIP "
+                                   "start-up and a pageable-memory PCIe copy of the parsed points"}
+            return {"end_to_end": e2e, "value": tests / phases["count"], "unit": "pairs-tested/s", "cores": cores, "kind": "reference",
                     "sample": sample_desc, "phases_s": phases, "wall_s": wall, "pairs": count,
                     "matches_hip_count": count == gpu_pairs,
                     "value_whole_path": tests / (phases["parsing"] + phases["flatten"] + phases["count"]),

@@ -1,0 +1,71 @@
+"""GPU: the C host program (same command line as the reference's ./main) and the
+sharded streaming helper, end to end on the golden inputs."""
+import importlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ht(psa):
+    return importlib.import_module("particle_simulation_amd.hosttools")
+
+
+def test_main_prints_the_reference_count(ht, golden_dir):
+    with open(os.path.join(golden_dir, "counts.json")) as f:
+        counts = json.load(f)
+    for name, info in counts.items():
+        for p in ("1", "4", "7"):
+            r = subprocess.run([ht.MAIN_PATH, "-f", os.path.join(golden_dir, name), "-p", p, "-c", "3"],
+                               capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, (name, r.stderr)
+            assert r.stdout == "%d\n" % info["count"], (name, p, r.stdout)     # exactly "%ld\n" (main.c:336)
+
+
+def test_main_on_generated_file_with_timer(ht, oracle, tmp_path):
+    path = str(tmp_path / "u300k.xyz")
+    n = ht.generate_text(path, ht.UNIFORM, 3, 300_000)
+    xyz = ht.generate(ht.UNIFORM, 3, 300_000)
+    # squeeze into a box so that there are pairs: regenerate as blobs instead
+    path2 = str(tmp_path / "b300k.xyz")
+    ht.generate_text(path2, ht.BLOBS, 3, 300_000, 150_000)
+    pts = ht.generate(ht.BLOBS, 3, 300_000, 150_000)
+    want, tests = oracle.count_pairs(pts)
+    env = dict(os.environ, PAIRCOUNT_TIMER="1")
+    r = subprocess.run([ht.MAIN_PATH, "-f", path2, "-p", "8"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr
+    assert int(r.stdout) == want and want > 0
+    for phase in ("init", "parsing", "binning", "count"):
+        assert phase in r.stderr
+    assert ("tests:  %10d" % tests) in r.stderr or str(tests) in r.stderr
+    r = subprocess.run([ht.MAIN_PATH, "-f", path, "-p", "3"], capture_output=True, text=True, timeout=120)
+    assert int(r.stdout) == oracle.count_pairs(xyz)[0] and n == 300_000
+
+
+def test_main_reports_tokenizer_errors_like_the_reference(ht, tmp_path):
+    bad = tmp_path / "bad.xyz"
+    bad.write_text("1.000000 2.000000 3.000000\n12.500000 1.000000 1.000000\n" * 8)
+    r = subprocess.run([ht.MAIN_PATH, "-f", str(bad)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 255 and "*str != '.'" in r.stderr
+
+
+def test_sharded_count_single_rank_and_manual_slabs(psa, ht, oracle):
+    import torch
+    sh = importlib.import_module("particle_simulation_amd.sharding")
+    pts = ht.generate(ht.BLOBS, 9, 400_000, 200_000)
+    want, _ = oracle.count_pairs(pts)
+    dev = torch.device("cuda", 0)
+    assert sh.sharded_count(pts, 0, 400, dev) == want
+    pop = np.bincount(oracle.cell_keys(pts) // (403 * 403), minlength=400)[:400].astype(np.float64)
+    cuts = sh.balanced_cuts(pop * pop, 4)
+    total = 0
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        x0, x1 = sh.halo_range(lo, hi)
+        mine = ht.generate(ht.BLOBS, 9, 400_000, 200_000, x_lo=x0, x_hi=x1)
+        total += sh.sharded_count(mine, lo, hi, dev)          # one "rank" after another on one GPU
+    assert total == want
