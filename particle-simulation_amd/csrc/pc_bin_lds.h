@@ -295,8 +295,8 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
 // No workgroup barrier and no staging buffer: a pencil's sorted points land in a
 // window of a few KB that this one wave writes completely, so the 12-byte stores,
 // scattered inside that window, merge into full lines in the XCD's L2.
-#define PC_L7_WAVES 4
-#define PC_L7_CAP 1024                                 // points a wave keeps in registers
+#define PC_L7_WAVES 2
+#define PC_L7_CAP 768                                  // points a wave keeps in registers and stages in LDS
 #define PC_L7_PPL (PC_L7_CAP / 64)
 
 
@@ -325,6 +325,7 @@ pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
                    int32_t *__restrict__ status)
 {
     __shared__ uint32_t hist_all[PC_L7_WAVES][PC_L_BINS];
+    __shared__ __attribute__((aligned(16))) float stage_all[PC_L7_WAVES][PC_L7_CAP * 3 + 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t *hist = hist_all[wave];
     const uint32_t pencil = blockIdx.x * PC_L7_WAVES + wave;
@@ -362,9 +363,31 @@ pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
         pc_l7_scan_bins(hist, lane);                   // hist now holds the exclusive starts
         pc_wave_lds_sync();
         for (int k = lane; k < PC_NBB; k += 64) slice[k] = base + hist[k];
+        // The pencil in cell order goes through LDS and leaves as 16-byte stores.
+        // `shift` gives the staged copy the same position modulo 16 bytes as its
+        // destination, so every aligned 16-byte LDS read feeds an aligned global store.
+        float *stage = stage_all[wave];
+        float *od = reinterpret_cast<float *>(o);
+        const uint32_t shift = (uint32_t)((reinterpret_cast<uintptr_t>(od) >> 2) & 3u);
+        uint32_t kept = 0;
 #pragma unroll
-        for (int j = 0; j < PC_L7_PPL; j++)
-            if (j < rounds && tag[j] != 0xFFFFFFFFu) o[hist[tag[j] & 1023u] + (tag[j] >> 10)] = pt[j];
+        for (int j = 0; j < PC_L7_PPL; j++) {
+            if (j < rounds && tag[j] != 0xFFFFFFFFu) {
+                const uint32_t pos = shift + 3u * (hist[tag[j] & 1023u] + (tag[j] >> 10));
+                stage[pos] = pt[j].x; stage[pos + 1] = pt[j].y; stage[pos + 2] = pt[j].z;
+                kept++;
+            }
+        }
+        kept = pc_wave_sum(kept);
+        pc_wave_lds_sync();
+        const uint32_t nd = 3u * kept;
+        const uint32_t head = min((4u - shift) & 3u, nd);          // dwords before the first 16-byte boundary
+        const uint32_t nbody = (nd - head) >> 2;
+        if ((uint32_t)lane < head) od[lane] = stage[shift + lane];
+        for (uint32_t q = lane; q < nbody; q += 64)
+            *reinterpret_cast<float4 *>(od + head + 4u * q) = *reinterpret_cast<const float4 *>(stage + shift + head + 4u * q);
+        const uint32_t t0 = head + 4u * nbody;
+        if ((uint32_t)lane < nd - t0) od[t0 + lane] = stage[shift + t0 + lane];
     } else {
         // more points than the registers hold: histogram sweep, then a second sweep
         // that claims slots through LDS cursors
