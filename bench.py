@@ -187,9 +187,23 @@ def main():
         bin_ms = sum(k["avg_ms"] * k["launches_per_step"] for nm, k in kernels.items() if not nm.startswith("pc_c"))
         cnt_ms = sum(k["avg_ms"] * k["launches_per_step"] for nm, k in kernels.items() if nm.startswith("pc_c"))
         dk = kernels[dom]
+        # HBM traffic per launch of the dominant kernel: not measurable from inside this process; taken from
+        # the committed rocprofv3 --pmc passes of the same workload (profiles/*traffic_<workload>.json,
+        # produced by tools/pmc_to_traffic.py, gfx950 FETCH_SIZE correction applied there), else null
+        traffic = None
+        if world == 1 and not args.points:
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic_%s.json" % args.workload)))
+            if files:
+                with open(files[-1]) as f:
+                    tk = json.load(f).get("kernels", {}).get(dom)
+                if tk:
+                    traffic = tk["hbm_bytes"] / 1e9
+                    dk["traffic_source"] = os.path.relpath(files[-1], ROOT)
         roofline = {
             "kernel": dom, "bound": "hbm", "achieved": dk.get("achieved_gbs"), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": (dk.get("achieved_gbs") or 0.0) / HBM_PEAK_GBS, "traffic": None,
+            "unit": "GB/s", "frac": (dk.get("achieved_gbs") or 0.0) / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_unit": "GB per launch (PMC, committed profile)", "algorithmic_gb": dk.get("algorithmic_gb"),
             "avg_launch_ms": dk["avg_ms"],
         }
         binning_alg_gb = (44 * n + 8 * (layers + 1) * 403 * 403) / 1e9
