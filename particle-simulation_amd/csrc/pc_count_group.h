@@ -26,27 +26,46 @@
 #include "pc_device.h"
 
 #define PC_G_WAVES 1
-#define PC_G_CAPM 448                   // merged candidates (rows 1-4) per window
-#define PC_G_CAPH 144                   // row-0 points per window
+#define PC_G_CAPM 448                   // merged candidates (rows 1-4) per window; a multiple of 64
+#define PC_G_CAPH 128                   // row-0 points per window; a multiple of 64
 #define PC_G_BAND (PC_NLAYERS / 8)
 #define PC_G_QUEUE_STRIDE 32             // one work counter per XCD group, each on its own 128-byte line
 #define PC_G_WG_PER_BAND ((PC_G_BAND + PC_G_WAVES - 1) / PC_G_WAVES)
 
 typedef float pc_v2f __attribute__((ext_vector_type(2)));
 struct pc_f3 { float x, y, z; };          // one point as stored in the sorted array (12 bytes, 4-byte aligned)
-struct pc_h6 { pc_v2f x, y, z; };         // a home particle as {x,x},{y,y},{z,z}: ready-made operands for packed math
-__device__ __forceinline__ pc_h6 pc_make_h6(float x, float y, float z)
-{
-    pc_h6 h;
-    h.x = pc_v2f{x, x}; h.y = pc_v2f{y, y}; h.z = pc_v2f{z, z};
-    return h;
-}
 
 struct pc_group_lds {
-    float x[PC_G_CAPM], y[PC_G_CAPM], z[PC_G_CAPM];   // merged rows 1-4 (reads may run past the end into h[])
-    pc_h6 h[PC_G_CAPH];                                // row 0: home cells and the cell above, coordinates duplicated
+    float x[PC_G_CAPM], y[PC_G_CAPM], z[PC_G_CAPM];   // merged rows 1-4 (reads may run past the end into the next arrays)
+    float hx[PC_G_CAPH], hy[PC_G_CAPH], hz[PC_G_CAPH]; // row 0: home cells and the cell above
     uint2 meta[PC_G_CAPH];                             // per home particle: .x = lo | hi<<16 (merged range), .y = end of its row-0 range
+    uint32_t src[PC_G_CAPM];                           // sorted-array slot of every merged candidate (gather list of the copy)
 };
+
+// Asynchronous copy of one dword per lane from global memory into LDS: lane t's
+// dword lands at lds_chunk[t].  The source address is per lane, the destination
+// is wave-uniform base + 4*lane (global_load_lds_dword); byte_offset is added to
+// both addresses by the instruction, hence the compensation on the LDS side.
+typedef __attribute__((address_space(3))) void pc_lds_void;
+typedef const __attribute__((address_space(1))) void pc_glb_void;
+template <int BYTE_OFFSET>
+__device__ __forceinline__ void pc_dma_dword(const float *g, float *lds_chunk)
+{
+    __builtin_amdgcn_global_load_lds((pc_glb_void *)g, (pc_lds_void *)(reinterpret_cast<char *>(lds_chunk) - BYTE_OFFSET),
+                                     4, BYTE_OFFSET, 0);
+}
+// one point (x, y, z) per lane into three separate arrays
+__device__ __forceinline__ void pc_dma_point(const float *g, float *lx, float *ly, float *lz)
+{
+    pc_dma_dword<0>(g, lx);
+    pc_dma_dword<4>(g, ly);
+    pc_dma_dword<8>(g, lz);
+}
+// the copies are complete (and visible to this wave's LDS reads) after this
+__device__ __forceinline__ void pc_dma_wait()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
 // One step of the candidate-parallel test: the wave handles 64/G home particles
 // [base, base+64/G); lane j of a group tests merged candidates lo+j+c*G, c=0..3,
@@ -60,12 +79,12 @@ __device__ __forceinline__ uint32_t pc_g_steps(const pc_group_lds &L, uint32_t n
     for (uint32_t base = 0; base < nh; base += 64 / G) {
         const uint32_t hp = min(base + grp, nh - 1);
         const uint2 m = L.meta[hp];
-        const pc_h6 a = L.h[hp];
+        const float hx = L.hx[hp], hy = L.hy[hp], hz = L.hz[hp];
         const bool live = base + grp < nh;
         uint32_t p = (m.x & 0xFFFFu) + j;
         // candidates this lane still has to test, counted in units of one: slot c is live iff rem > c*G
         int rem = live ? (int)(m.x >> 16) - (int)p : 0;
-        const pc_v2f ax = a.x, ay = a.y, az = a.z;
+        const pc_v2f ax = {hx, hx}, ay = {hy, hy}, az = {hz, hz};    // splat operands of the packed math
         for (;;) {
             const pc_v2f x01 = {L.x[p], L.x[p + G]}, x23 = {L.x[p + 2 * G], L.x[p + 3 * G]};
             const pc_v2f y01 = {L.y[p], L.y[p + G]}, y23 = {L.y[p + 2 * G], L.y[p + 3 * G]};
@@ -90,8 +109,8 @@ __device__ __forceinline__ uint32_t pc_g_steps(const pc_group_lds &L, uint32_t n
         uint32_t p0 = hp + 1 + j;
         int rem0 = live ? (int)m.y - (int)p0 : 0;
         for (;;) {
-            const pc_h6 &v = L.h[min(p0, (uint32_t)PC_G_CAPH - 1)];
-            const float dx = ax.x - v.x.x, dy = ay.x - v.y.x, dz = az.x - v.z.x;
+            const uint32_t pc = min(p0, (uint32_t)PC_G_CAPH - 1);
+            const float dx = hx - L.hx[pc], dy = hy - L.hy[pc], dz = hz - L.hz[pc];
             const float sq = (dx * dx + dy * dy) + dz * dz;
             hits += __popcll(__builtin_amdgcn_ballot_w64(sq <= 0.0025f) & __builtin_amdgcn_ballot_w64(rem0 > 0));
             rem0 -= G;
@@ -123,8 +142,8 @@ __device__ __forceinline__ uint32_t pc_g_block(const pc_group_lds &L, uint32_t c
         const unsigned long long m0 = __builtin_amdgcn_ballot_w64(p < c_hi), m1 = __builtin_amdgcn_ballot_w64(p + 64 < c_hi),
                                  m2 = __builtin_amdgcn_ballot_w64(p + 128 < c_hi), m3 = __builtin_amdgcn_ballot_w64(p + 192 < c_hi);
         for (uint32_t hp = h_lo; hp < h_hi; hp++) {
-            const pc_h6 a = L.h[hp];
-            const pc_v2f ax = a.x, ay = a.y, az = a.z;
+            const float hx = L.hx[hp], hy = L.hy[hp], hz = L.hz[hp];
+            const pc_v2f ax = {hx, hx}, ay = {hy, hy}, az = {hz, hz};
             const pc_v2f dx01 = ax - x01, dy01 = ay - y01, dz01 = az - z01;
             const pc_v2f dx23 = ax - x23, dy23 = ay - y23, dz23 = az - z23;
             const pc_v2f s01 = (dx01 * dx01 + dy01 * dy01) + dz01 * dz01;
@@ -236,47 +255,41 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                 const uint32_t hi_h = __shfl_down(cum_h, 1, 64);           // end of cell t+1 in h[]
                 done = __shfl(s[0], t_last, 64);                           // start of the last window cell = next first home cell
                 if (nh != 0) {
-                    // ---- merged copy of rows 1-4: lane t copies its cell's points, which
-                    //      land at ex_m + v for v = 0..nm-1 in row order.  Eight loads
-                    //      are issued before the first store (one memory round trip per
-                    //      batch instead of one per point).
-                    const uint32_t mine = lane <= t_last ? nm : 0u;
-                    const uint32_t pre1 = n[1], pre2 = pre1 + n[2], pre3 = pre2 + n[3];
-                    for (uint32_t v0 = 0; __builtin_amdgcn_ballot_w64(v0 < mine) != 0; v0 += 8) {
-                        pc_f3 buf[8];
+                    // ---- merged copy of rows 1-4, in two stages.  Stage 1, lane t = cell t:
+                    //      write the sorted-array slot of each of the cell's points to the
+                    //      gather list, row after row (they land at ex_m + 0..nm-1).
+                    {
+                        uint32_t o = ex_m;
 #pragma unroll
-                        for (int qq = 0; qq < 8; qq++) {
-                            const uint32_t v = v0 + qq;
-                            uint32_t src = v < pre1 ? s[1] + v : v < pre2 ? s[2] + (v - pre1)
-                                         : v < pre3 ? s[3] + (v - pre2) : s[4] + (v - pre3);
-                            if (v >= mine) src = home_lo;                  // harmless valid address
-                            buf[qq] = *reinterpret_cast<const pc_f3 *>(pts + 3 * (uint64_t)src);
-                        }
-#pragma unroll
-                        for (int qq = 0; qq < 8; qq++) {
-                            const uint32_t v = v0 + qq;
-                            if (v < mine) { L.x[ex_m + v] = buf[qq].x; L.y[ex_m + v] = buf[qq].y; L.z[ex_m + v] = buf[qq].z; }
+                        for (int r = 1; r < 5; r++) {
+                            const uint32_t nr = lane <= t_last ? n[r] : 0u;
+                            for (uint32_t v = 0; __builtin_amdgcn_ballot_w64(v < nr) != 0; v++)
+                                if (v < nr) L.src[o + v] = s[r] + v;
+                            o += nr;
                         }
                     }
-                    // ---- row 0: one contiguous run of at most PC_G_CAPH points, all lanes
-                    {
-                        pc_f3 buf[(PC_G_CAPH + 63) / 64];
+                    pc_wave_lds_sync();
+                    // ---- stage 2, lane = merged slot: gather the points through the list,
+                    //      straight into LDS by the DMA path (no registers, no LDS stores)
+                    for (uint32_t q0 = 0; q0 < tot_m; q0 += 64) {
+                        const uint32_t q = q0 + lane;
+                        const uint32_t src = q < tot_m ? L.src[q] : home_lo;
+                        pc_dma_point(pts + 3 * (uint64_t)src, L.x + q0, L.y + q0, L.z + q0);
+                    }
+                    // ---- row 0: one contiguous run of at most PC_G_CAPH points
 #pragma unroll
-                        for (int qq = 0; qq < (PC_G_CAPH + 63) / 64; qq++) {
-                            const uint32_t e = lane + 64 * qq;
-                            buf[qq] = *reinterpret_cast<const pc_f3 *>(pts + 3 * (uint64_t)(e < tot_h ? h_first + e : home_lo));
-                        }
-#pragma unroll
-                        for (int qq = 0; qq < (PC_G_CAPH + 63) / 64; qq++) {
-                            const uint32_t e = lane + 64 * qq;
-                            if (e < tot_h) L.h[e] = pc_make_h6(buf[qq].x, buf[qq].y, buf[qq].z);
-                        }
+                    for (int qq = 0; qq < PC_G_CAPH / 64; qq++) {
+                        const uint32_t e = lane + 64 * qq;
+                        if (64u * qq < tot_h)
+                            pc_dma_point(pts + 3 * (uint64_t)(e < tot_h ? h_first + e : home_lo),
+                                         L.hx + 64 * qq, L.hy + 64 * qq, L.hz + 64 * qq);
                     }
                     // ---- per home particle: its merged candidate range and the end of its row-0 range
                     if (lane >= th0 && lane < t_last) {
                         const uint32_t lo = lane > 0 ? lo_m : 0u;
                         for (uint32_t u = 0; u < n[0]; u++) L.meta[ex_h + u] = make_uint2(lo | (hi_m << 16), hi_h);
                     }
+                    pc_dma_wait();
                     pc_wave_lds_sync();
                     // ---- rows 1-4: candidate-parallel steps, group size from the mean range length
                     // slots = 4G should cover mean + 2 sigma of a Poisson range length:
@@ -299,13 +312,11 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                         }
                         // same pencil (the steps above count these themselves): lane per home particle
                         for (uint32_t hp = lane; hp < nh; hp += 64) {
-                            const pc_h6 &me = L.h[hp];
+                            const float mx = L.hx[hp], my = L.hy[hp], mz = L.hz[hp];
                             const uint32_t end = L.meta[hp].y;
                             uint32_t cnt = 0;
-                            for (uint32_t k2 = hp + 1; k2 < end; k2++) {
-                                const pc_h6 &v = L.h[k2];
-                                cnt += pc_hit(me.x.x, me.y.x, me.z.x, v.x.x, v.y.x, v.z.x);
-                            }
+                            for (uint32_t k2 = hp + 1; k2 < end; k2++)
+                                cnt += pc_hit(mx, my, mz, L.hx[k2], L.hy[k2], L.hz[k2]);
                             acc += cnt;
                         }
                     }
@@ -330,35 +341,29 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                     if (h0 == h1) break;                   // no home particle in this cell
                     for (uint32_t p0 = c_lo[r]; p0 < c_hi[r]; p0 += PC_G_CAPM) {
                         const uint32_t cnt = min((uint32_t)PC_G_CAPM, c_hi[r] - p0);
-                        {
-                            pc_f3 buf[PC_G_CAPM / 64];
 #pragma unroll
-                            for (int qq = 0; qq < PC_G_CAPM / 64; qq++) {
-                                const uint32_t e = lane + 64 * qq;
-                                buf[qq] = *reinterpret_cast<const pc_f3 *>(pts + 3 * (uint64_t)(e < cnt ? p0 + e : p0));
-                            }
-#pragma unroll
-                            for (int qq = 0; qq < PC_G_CAPM / 64; qq++) {
-                                const uint32_t e = lane + 64 * qq;
-                                if (e < cnt) { L.x[e] = buf[qq].x; L.y[e] = buf[qq].y; L.z[e] = buf[qq].z; }
-                            }
+                        for (int qq = 0; qq < PC_G_CAPM / 64; qq++) {
+                            const uint32_t e = lane + 64 * qq;
+                            if (64u * qq < cnt)
+                                pc_dma_point(pts + 3 * (uint64_t)(e < cnt ? p0 + e : p0), L.x + 64 * qq, L.y + 64 * qq, L.z + 64 * qq);
                         }
                         // the cell's home particles in batches: every lane works on the
                         // piece's candidates for one home particle at a time (G = 64)
                         for (uint32_t hb = h0; hb < h1; hb += PC_G_CAPH) {
                             const uint32_t nhb = min((uint32_t)PC_G_CAPH, h1 - hb);
 #pragma unroll
-                            for (int qq = 0; qq < (PC_G_CAPH + 63) / 64; qq++) {
+                            for (int qq = 0; qq < PC_G_CAPH / 64; qq++) {
                                 const uint32_t e = lane + 64 * qq;
+                                if (64u * qq < nhb)
+                                    pc_dma_point(pts + 3 * (uint64_t)(e < nhb ? hb + e : hb), L.hx + 64 * qq, L.hy + 64 * qq, L.hz + 64 * qq);
                                 if (e < nhb) {
                                     const uint32_t i = hb + e;
-                                    const pc_f3 v = *reinterpret_cast<const pc_f3 *>(pts + 3 * (uint64_t)i);
                                     uint32_t lo = 0;
                                     if (r == 0 && i + 1 > p0) lo = min(i + 1 - p0, cnt);   // row 0: only slots after i
-                                    L.h[e] = pc_make_h6(v.x, v.y, v.z);
                                     L.meta[e] = make_uint2(lo | (cnt << 16), 0u);
                                 }
                             }
+                            pc_dma_wait();
                             pc_wave_lds_sync();
                             const uint32_t hits = r == 0 ? pc_g_block<true>(L, 0, cnt, 0, nhb, lane)
                                                          : pc_g_block<false>(L, 0, cnt, 0, nhb, lane);
