@@ -23,6 +23,7 @@
 // one 64-bit atomic per workgroup.  Workgroup -> pencil mapping is XCD-aware as
 // in variant 2 (speed only).
 #pragma once
+#include <utility>
 #include "pc_device.h"
 
 #define PC_G_WAVES 1
@@ -35,7 +36,7 @@
 typedef float pc_v2f __attribute__((ext_vector_type(2)));
 struct pc_f3 { float x, y, z; };          // one point as stored in the sorted array (12 bytes, 4-byte aligned)
 
-struct pc_group_lds {
+struct alignas(16) pc_group_lds {
     float x[PC_G_CAPM], y[PC_G_CAPM], z[PC_G_CAPM];   // merged rows 1-4 (reads may run past the end into the next arrays)
     float hx[PC_G_CAPH], hy[PC_G_CAPH], hz[PC_G_CAPH]; // row 0: home cells and the cell above
     uint2 meta[PC_G_CAPH];                             // per home particle: .x = lo | hi<<16 (merged range), .y = end of its row-0 range
@@ -67,54 +68,102 @@ __device__ __forceinline__ void pc_dma_wait()
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// One step of the candidate-parallel test: the wave handles 64/G home particles
-// [base, base+64/G); lane j of a group tests merged candidates lo+j+c*G, c=0..3,
-// and loops in strides of 4G while any group has candidates left.
-template <int G>
+// Two neighbouring floats at an even index of an 8-byte aligned LDS array as ONE
+// ds_read_b64.  Written as inline assembly because the compiler either assumes
+// 4-byte alignment (two half-rate 4-byte reads) or, told the alignment, fuses two
+// such reads into a ds_read2_b64, which the LDS serves at half the rate of two
+// separate ds_read_b64.  The compiler does not track these reads: the values may
+// be used only after pc_lds_pairs_arrived() has been applied to them.
+template <int BYTE_OFFSET>
+__device__ __forceinline__ pc_v2f pc_lds_pair(uint32_t lds_byte_addr)
+{
+    pc_v2f v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(lds_byte_addr), "n"(BYTE_OFFSET));
+    return v;
+}
+__device__ __forceinline__ void pc_lds_pairs_arrived(pc_v2f &a, pc_v2f &b, pc_v2f &c)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c) : : "memory");
+}
+// pairs c = 0..NP-1 of a lane: candidates 2*G*c and 2*G*c + 1 past the lane's first, from the three coordinate arrays
+template <int G, int... C>
+__device__ __forceinline__ void pc_lds_pairs_request(uint32_t ap, pc_v2f *x, pc_v2f *y, pc_v2f *z, std::integer_sequence<int, C...>)
+{
+    ((x[C] = pc_lds_pair<8 * G * C>(ap), y[C] = pc_lds_pair<4 * PC_G_CAPM + 8 * G * C>(ap),
+      z[C] = pc_lds_pair<8 * PC_G_CAPM + 8 * G * C>(ap)), ...);
+}
+__device__ __forceinline__ uint32_t pc_lds_addr(const void *p)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+
+// Candidate-parallel test of the nh home particles staged in LDS.  A group of G
+// lanes takes one home particle, so the wave handles 64/G of them per step; lane
+// j of a group tests the candidate pairs (lo + 2j + 2G*c, +1), c = 0..NP-1, i.e.
+// 2*G*NP candidates per home particle and pass, and the pass repeats while any
+// group has candidates left.  Ranges start and end on even slots (cell blocks
+// are padded with a never-matching point), so a pair is one aligned 8-byte LDS
+// read and is live or dead as a whole.
+template <int G, int NP>
 __device__ __forceinline__ uint32_t pc_g_steps(const pc_group_lds &L, uint32_t nh, int lane)
 {
+    constexpr int NP0 = G >= 4 ? 1 : 4 / G;             // same-pencil pairs per lane: at least 8 candidates per group
     uint32_t hits = 0;
     const uint32_t j = lane & (G - 1), grp = lane / G;
     nh = __builtin_amdgcn_readfirstlane(nh);             // wave-uniform: keep the step loop scalar
+    const uint32_t ax_lds = pc_lds_addr(L.x);
     for (uint32_t base = 0; base < nh; base += 64 / G) {
         const uint32_t hp = min(base + grp, nh - 1);
         const uint2 m = L.meta[hp];
         const float hx = L.hx[hp], hy = L.hy[hp], hz = L.hz[hp];
         const bool live = base + grp < nh;
-        uint32_t p = (m.x & 0xFFFFu) + j;
-        // candidates this lane still has to test, counted in units of one: slot c is live iff rem > c*G
+        uint32_t p = (m.x & 0xFFFFu) + 2 * j;
+        // candidates from p to the end of the range (even, or <= 0): pair c is live iff rem > 2*G*c
         int rem = live ? (int)(m.x >> 16) - (int)p : 0;
         const pc_v2f ax = {hx, hx}, ay = {hy, hy}, az = {hz, hz};    // splat operands of the packed math
         for (;;) {
-            const pc_v2f x01 = {L.x[p], L.x[p + G]}, x23 = {L.x[p + 2 * G], L.x[p + 3 * G]};
-            const pc_v2f y01 = {L.y[p], L.y[p + G]}, y23 = {L.y[p + 2 * G], L.y[p + 3 * G]};
-            const pc_v2f z01 = {L.z[p], L.z[p + G]}, z23 = {L.z[p + 2 * G], L.z[p + 3 * G]};
-            // (dx*dx + dy*dy) + dz*dz, each step rounded separately (no contraction: see build flags)
-            const pc_v2f dx01 = ax - x01, dy01 = ay - y01, dz01 = az - z01;
-            const pc_v2f dx23 = ax - x23, dy23 = ay - y23, dz23 = az - z23;
-            const pc_v2f s01 = (dx01 * dx01 + dy01 * dy01) + dz01 * dz01;
-            const pc_v2f s23 = (dx23 * dx23 + dy23 * dy23) + dz23 * dz23;
+            pc_v2f x[NP], y[NP], z[NP], sq[NP];
+            const uint32_t ap = ax_lds + 4 * p;          // LDS byte address of x[p]; y and z are whole arrays further
+            pc_lds_pairs_request<G>(ap, x, y, z, std::make_integer_sequence<int, NP>());
+#pragma unroll
+            for (int c = 0; c < NP; c++) {
+                pc_lds_pairs_arrived(x[c], y[c], z[c]);
+                // (dx*dx + dy*dy) + dz*dz, each step rounded separately (no contraction: see build flags)
+                const pc_v2f dx = ax - x[c], dy = ay - y[c], dz = az - z[c];
+                sq[c] = (dx * dx + dy * dy) + dz * dz;
+            }
             // one ballot per compare, masks combined on the scalar unit (a ballot of
             // "a && b" would be materialised through a 0/1 VGPR and compared again)
-            hits += __popcll(__builtin_amdgcn_ballot_w64(s01.x <= 0.0025f) & __builtin_amdgcn_ballot_w64(rem > 0));
-            hits += __popcll(__builtin_amdgcn_ballot_w64(s01.y <= 0.0025f) & __builtin_amdgcn_ballot_w64(rem > G));
-            hits += __popcll(__builtin_amdgcn_ballot_w64(s23.x <= 0.0025f) & __builtin_amdgcn_ballot_w64(rem > 2 * G));
-            hits += __popcll(__builtin_amdgcn_ballot_w64(s23.y <= 0.0025f) & __builtin_amdgcn_ballot_w64(rem > 3 * G));
-            rem -= 4 * G;
-            p += 4 * G;
+#pragma unroll
+            for (int c = 0; c < NP; c++) {
+                const unsigned long long ok = __builtin_amdgcn_ballot_w64(rem > 2 * G * c);
+                hits += __popcll(__builtin_amdgcn_ballot_w64(sq[c].x <= 0.0025f) & ok)
+                      + __popcll(__builtin_amdgcn_ballot_w64(sq[c].y <= 0.0025f) & ok);
+            }
+            rem -= 2 * G * NP;
+            p += 2 * G * NP;
             if (__builtin_amdgcn_ballot_w64(rem > 0) == 0) break;
         }
-        // same pencil: later points of the home cell and the cell above are h[hp+1 .. m.y),
-        // one candidate per lane of the group (main.c:215-221 and offset (0,0,1))
-        uint32_t p0 = hp + 1 + j;
-        int rem0 = live ? (int)m.y - (int)p0 : 0;
+        // same pencil: later points of the home cell and the cell above are row-0 slots
+        // hp+1 .. m.y-1 (main.c:215-221 and offset (0,0,1)); two neighbouring slots per lane and pass
+        uint32_t p0 = hp + 1 + 2 * j;
+        int rem0 = live ? (int)m.y - (int)p0 : 0;         // slots from p0 to the end: slot u of pair c is live iff rem0 > 2*G*c + u
         for (;;) {
-            const uint32_t pc = min(p0, (uint32_t)PC_G_CAPH - 1);
-            const float dx = hx - L.hx[pc], dy = hy - L.hy[pc], dz = hz - L.hz[pc];
-            const float sq = (dx * dx + dy * dy) + dz * dz;
-            hits += __popcll(__builtin_amdgcn_ballot_w64(sq <= 0.0025f) & __builtin_amdgcn_ballot_w64(rem0 > 0));
-            rem0 -= G;
-            p0 += G;
+            pc_v2f sq[NP0];
+#pragma unroll
+            for (int c = 0; c < NP0; c++) {
+                const uint32_t pc = p0 + 2 * G * c;       // dead slots may lie past the row-0 arrays, still inside the LDS block
+                const pc_v2f x = {L.hx[pc], L.hx[pc + 1]}, y = {L.hy[pc], L.hy[pc + 1]}, z = {L.hz[pc], L.hz[pc + 1]};
+                const pc_v2f dx = ax - x, dy = ay - y, dz = az - z;
+                sq[c] = (dx * dx + dy * dy) + dz * dz;
+            }
+#pragma unroll
+            for (int c = 0; c < NP0; c++) {
+                hits += __popcll(__builtin_amdgcn_ballot_w64(sq[c].x <= 0.0025f) & __builtin_amdgcn_ballot_w64(rem0 > 2 * G * c))
+                      + __popcll(__builtin_amdgcn_ballot_w64(sq[c].y <= 0.0025f) & __builtin_amdgcn_ballot_w64(rem0 > 2 * G * c + 1));
+            }
+            rem0 -= 2 * G * NP0;
+            p0 += 2 * G * NP0;
             if (__builtin_amdgcn_ballot_w64(rem0 > 0) == 0) break;
         }
     }
@@ -227,7 +276,10 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                 n[r] = (valid[r] && zl + lane < PC_NBB - 1) ? a1[r] - a0[r] : 0u;
             }
             if (lane < th0) n[0] = 0;                      // row-0 points below the first home cell are not needed
-            const uint32_t nm = n[1] + n[2] + n[3] + n[4];
+            // merged points of the cell, and its block length in the merged array: padded to
+            // an even count, so every candidate range starts and ends on an even slot
+            const uint32_t nm_pts = n[1] + n[2] + n[3] + n[4];
+            const uint32_t nm = (nm_pts + 1) & ~1u;
             const uint32_t cum_m = pc_wave_incl_scan(nm), cum_h = pc_wave_incl_scan(n[0]);
             // longest window that fits both buffers (feasible lanes form a prefix)
             const int nfit = __popcll(__builtin_amdgcn_ballot_w64(cum_m <= PC_G_CAPM && cum_h <= PC_G_CAPH));
@@ -267,6 +319,7 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                                 if (v < nr) L.src[o + v] = s[r] + v;
                             o += nr;
                         }
+                        if (lane <= t_last && (nm_pts & 1)) L.src[o] = home_lo;   // the pad slot copies any valid point ...
                     }
                     pc_wave_lds_sync();
                     // ---- stage 2, lane = merged slot: gather the points through the list,
@@ -290,17 +343,18 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                         for (uint32_t u = 0; u < n[0]; u++) L.meta[ex_h + u] = make_uint2(lo | (hi_m << 16), hi_h);
                     }
                     pc_dma_wait();
+                    if (lane <= t_last && (nm_pts & 1)) L.x[ex_m + nm_pts] = __builtin_nanf("");   // ... and then never matches
                     pc_wave_lds_sync();
                     // ---- rows 1-4: candidate-parallel steps, group size from the mean range length
-                    // slots = 4G should cover mean + 2 sigma of a Poisson range length:
+                    // candidates per pass (2*G*NP) should cover mean + 2 sigma of a Poisson range length:
                     // m + 2*sqrt(m) + 1 <= 8, 16, 32, 64, 128  <=>  m <= 3, 9, 22, 49, 106
                     const uint32_t mean3 = 3u * tot_m / (uint32_t)(t_last + 1);
                     uint32_t hits;
-                    if (mean3 <= 3) hits = pc_g_steps<2>(L, nh, lane);
-                    else if (mean3 <= 9) hits = pc_g_steps<4>(L, nh, lane);
-                    else if (mean3 <= 22) hits = pc_g_steps<8>(L, nh, lane);
-                    else if (mean3 <= 49) hits = pc_g_steps<16>(L, nh, lane);
-                    else if (mean3 <= 106) hits = pc_g_steps<32>(L, nh, lane);
+                    if (mean3 <= 3) hits = pc_g_steps<2, 2>(L, nh, lane);
+                    else if (mean3 <= 9) hits = pc_g_steps<2, 4>(L, nh, lane);
+                    else if (mean3 <= 22) hits = pc_g_steps<2, 8>(L, nh, lane);
+                    else if (mean3 <= 49) hits = pc_g_steps<4, 8>(L, nh, lane);
+                    else if (mean3 <= 106) hits = pc_g_steps<8, 8>(L, nh, lane);
                     else {
                         // dense window: per home cell, candidates stay in registers while the
                         // cell's home particles stream by
