@@ -149,6 +149,15 @@ int pc_set_variant(const char *name, int value);
 int pc_profile_enable(int on);
 int pc_profile_read(char *buf, size_t buflen);
 
+/* Self-check of the cell-index arithmetic: the kernels compute the index of
+   main.c:134-136 by a binary32 shortcut that falls back to the reference's
+   binary64 expression near cell boundaries.  This runs both over all 2^32
+   float bit patterns on the current device and adds the number of patterns on
+   which they differ to *d_mismatches (device memory, zeroed by the caller);
+   anything but 0 is a bug.  No counterpart in the reference; used by the GPU
+   test suite. */
+int pc_selfcheck_cell_index_device(uint64_t *d_mismatches, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

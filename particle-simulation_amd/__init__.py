@@ -53,6 +53,7 @@ ABI = [
     ("pc_set_variant", _i32, [_c.c_char_p, _i32]),
     ("pc_profile_enable", _i32, [_i32]),
     ("pc_profile_read", _i32, [_c.c_char_p, _sz]),
+    ("pc_selfcheck_cell_index_device", _i32, [_vp, _vp]),
 ]
 
 

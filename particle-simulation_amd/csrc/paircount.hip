@@ -162,7 +162,7 @@ extern "C" size_t pc_workspace_bytes(uint64_t n)
     size_t keys = align_up((size_t)n * 4 + 4, 256);
     size_t sums = align_up((size_t)scan_tiles(PC_NCELLS + 2) * 4, 256);
     size_t v0 = keys + sums + 256;
-    size_t v1 = align_up((size_t)n * 12 + 16, 256) + align_up(lds_ws_counters(n) * 4, 256) + 256;
+    size_t v1 = align_up((size_t)n * 12 + 16, 256) + align_up(lds_ws_counters(n) * 4, 256) + align_up((size_t)n * 2 + 16, 256) + 256;
     return v0 > v1 ? v0 : v1;
 }
 
@@ -179,6 +179,7 @@ static pc_lds_ws carve_lds_ws(void *ws, uint64_t n)
     w.tile_layer = u;             u += (n + PC_L_TILE - 1) / PC_L_TILE + PC_L_BINS;
     w.pencil_start = u;           u += PC_L_NPENCILS + 1;
     w.pencil_cursor = u;
+    w.ycell = (uint16_t *)((char *)ws + align_up((size_t)n * 12 + 16, 256) + align_up(lds_ws_counters(n) * 4, 256));
     return w;
 }
 
@@ -194,15 +195,15 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
               w.layer_tile, w.tile_layer);
     if (n) {
         PC_LAUNCH("pc_l3_partition_x", pc_l36_partition<0>, dim3(tiles), dim3(PC_L_PTPB), s, d_xyz, n, d_sorted,
-                  w.layer_start, w.layer_tile, w.tile_layer, w.layer_cursor);
-        PC_LAUNCH("pc_l4_hist_y", pc_l4_hist_y, dim3(tiles + PC_NBB), dim3(PC_L_TPB), s, d_sorted, w.layer_start,
+                  w.layer_start, w.layer_tile, w.tile_layer, w.layer_cursor, w.ycell);
+        PC_LAUNCH("pc_l4_hist_y", pc_l4_hist_y, dim3(tiles + PC_NBB), dim3(PC_L_TPB), s, w.ycell, w.layer_start,
                   w.layer_tile, w.tile_layer, w.pencil_count, d_status);
     }
     PC_LAUNCH("pc_l5_scan_y", pc_l5_scan_y, dim3(PC_NBB), dim3(512), s, w.pencil_count, w.layer_start,
               w.pencil_start, w.pencil_cursor);
     if (n)
         PC_LAUNCH("pc_l6_partition_y", pc_l36_partition<1>, dim3(tiles + PC_NBB), dim3(PC_L_PTPB), s, d_sorted, n,
-                  w.tmp, w.layer_start, w.layer_tile, w.tile_layer, w.pencil_cursor);
+                  w.tmp, w.layer_start, w.layer_tile, w.tile_layer, w.pencil_cursor, w.ycell);
     PC_LAUNCH("pc_l7_sort_pencils", pc_l7_sort_pencils, dim3((PC_L_NPENCILS + PC_L7_WAVES - 1) / PC_L7_WAVES),
               dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted, w.pencil_start, table, d_status);
     PC_HIP(hipGetLastError());
@@ -215,6 +216,15 @@ static inline int grid_for(uint64_t n, int tpb, int cap)
     if (g < 1) g = 1;
     if (g > (uint64_t)cap) g = cap;
     return (int)g;
+}
+
+extern "C" int pc_selfcheck_cell_index_device(uint64_t *d_mismatches, void *stream)
+{
+    if (!d_mismatches) return pc_fail(PC_ERR_ARG, "pc_selfcheck_cell_index_device: null pointer");
+    PC_LAUNCH("pc_selfcheck_cell_index", pc_selfcheck_cell_index, dim3(65536), dim3(256), (hipStream_t)stream,
+              (unsigned long long *)d_mismatches);
+    PC_HIP(hipGetLastError());
+    return PC_OK;
 }
 
 extern "C" int pc_cell_keys_device(const float *d_xyz, uint64_t n, uint32_t *d_keys,

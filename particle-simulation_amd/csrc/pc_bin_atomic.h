@@ -36,6 +36,20 @@ pc_a1_keys_hist(const float *__restrict__ xyz, uint64_t n, uint32_t *__restrict_
     if (bad) atomicOr(status, 1);
 }
 
+// every float bit pattern: shortcut index against the reference expression
+__global__ void __launch_bounds__(256)
+pc_selfcheck_cell_index(unsigned long long *__restrict__ mismatches)
+{
+    unsigned int bad = 0;
+    const uint32_t first = (blockIdx.x * 256u + threadIdx.x) * 256u;     // grid 65536 x 256 threads x 256 patterns = 2^32
+    for (uint32_t q = 0; q < 256u; q++) {
+        const float f = __uint_as_float(first + q);
+        if (f != f) continue;                                          // NaN: the conversion to int is not defined by the reference
+        bad += pc_cell_index(f) != pc_cell_index_exact(f);
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
 // keys only (the stage entry point pc_cell_keys_device)
 __global__ void __launch_bounds__(256)
 pc_keys_only(const float *__restrict__ xyz, uint64_t n, uint32_t *__restrict__ keys,

@@ -12,8 +12,11 @@
 // pass sorts a tile of points by bin inside LDS and then writes every bin's run
 // with coalesced dword stores, so all three passes stream at HBM rate.
 //
-// Data movement per point: L1 12 B read; L3, L6, L7 12 B read + 12 B write each;
-// L4 12 B read  => 96 B/point, plus 4 B per cell of table written by L7.
+// L3 also records every point's y cell (2 bytes, in level-X order), so the level-Y
+// histogram reads 2 bytes per point instead of the point itself.
+// Data movement per point: L1 12 B read; L3 12 B read + 14 B write; L4 2 B read;
+// L6 12 B read + 12 B write; L7 12 B read + 12 B write  => 88 B/point, plus 4 B per
+// cell of table written by L7.
 // The order of points inside a cell is unspecified (as in the reference).
 #pragma once
 #include "pc_device.h"
@@ -42,6 +45,7 @@ struct pc_lds_ws {
     uint32_t *tile_layer;     // [tiles+404] layer of each level-Y tile
     uint32_t *pencil_start;   // [162409+1]
     uint32_t *pencil_cursor;  // [NREP][PSTRIDE]
+    uint16_t *ycell;          // [N] y cell of every point of the level-X output (0xFFFF: outside the grid)
 };
 
 // ---- L1: histogram of x layers ---------------------------------------------
@@ -126,7 +130,7 @@ pc_l2_scan_x(const uint32_t *__restrict__ layer_count, uint32_t *__restrict__ la
 // ---- L4: histogram of pencils inside each layer ------------------------------
 // Level-Y tile b is chunk (b - layer_tile[layer]) of layer tile_layer[b].
 __global__ void __launch_bounds__(PC_L_TPB)
-pc_l4_hist_y(const float *__restrict__ pts, const uint32_t *__restrict__ layer_start,
+pc_l4_hist_y(const uint16_t *__restrict__ ycell, const uint32_t *__restrict__ layer_start,
              const uint32_t *__restrict__ layer_tile, const uint32_t *__restrict__ tile_layer,
              uint32_t *__restrict__ pencil_count, int32_t *__restrict__ status)
 {
@@ -137,17 +141,16 @@ pc_l4_hist_y(const float *__restrict__ pts, const uint32_t *__restrict__ layer_s
     const uint32_t first = layer_start[layer] + chunk * PC_L_TILE;
     const uint32_t cnt = min((uint32_t)PC_L_TILE, layer_start[layer + 1] - first);
     for (int b = threadIdx.x; b < PC_L_BINS; b += PC_L_TPB) h[b] = 0;
-    float ys[PC_L_PPT];
+    uint32_t ys[PC_L_PPT];
 #pragma unroll
     for (int j = 0; j < PC_L_PPT; j++)
-        ys[j] = pts[3 * ((uint64_t)first + min((uint32_t)(threadIdx.x + j * PC_L_TPB), cnt - 1)) + 1];
+        ys[j] = ycell[(uint64_t)first + min((uint32_t)(threadIdx.x + j * PC_L_TPB), cnt - 1)];
     __syncthreads();
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < PC_L_PPT; j++) {
         if ((uint32_t)(threadIdx.x + j * PC_L_TPB) < cnt) {
-            const int jy = pc_cell_index(ys[j]);
-            if ((unsigned)jy < 400u) atomicAdd(&h[jy], 1u);
+            if (ys[j] < 400u) atomicAdd(&h[ys[j]], 1u);
             else bad = true;
         }
     }
@@ -195,17 +198,18 @@ pc_l5_scan_y(const uint32_t *__restrict__ pencil_count, const uint32_t *__restri
 
 // ---- L3 / L6: partition a tile of points into 403 bins -----------------------
 // LEVEL 0: tile = points [blockIdx*TILE, +TILE) of the input, bin = x cell,
-//          cursors = layer_cursor.
-// LEVEL 1: tile = a chunk of one layer, bin = y cell, cursors = that layer's
-//          row of pencil_cursor.
+//          cursors = layer_cursor; writes ycell[] beside the points.
+// LEVEL 1: tile = a chunk of one layer, bin = y cell,
+//          cursors = that layer's row of pencil_cursor.
 template <int LEVEL>
 __global__ void __launch_bounds__(PC_L_PTPB)
 pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ dst,
                  const uint32_t *__restrict__ layer_start, const uint32_t *__restrict__ layer_tile,
-                 const uint32_t *__restrict__ tile_layer, uint32_t *__restrict__ cursor)
+                 const uint32_t *__restrict__ tile_layer, uint32_t *__restrict__ cursor, uint16_t *__restrict__ ycell)
 {
     __shared__ float buf[PC_L_TILE * 3];              // the tile sorted by bin
     __shared__ uint16_t bin_of[PC_L_TILE];
+    __shared__ uint16_t ycell_of[LEVEL == 0 ? PC_L_TILE : 1];
     __shared__ uint32_t hist[PC_L_BINS];
     __shared__ uint32_t lstart[PC_L_BINS];
     __shared__ uint32_t delta[PC_L_BINS];             // global slot of bin's first point minus lstart
@@ -231,6 +235,7 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
     // consecutive lanes on consecutive points); all loads are issued before any use
     const pc_pt3 *g = reinterpret_cast<const pc_pt3 *>(src) + first;
     pc_pt3 pt[PC_L_PPPT];
+    uint32_t yc[PC_L_PPPT];
 #pragma unroll
     for (int j = 0; j < PC_L_PPPT; j++) pt[j] = g[min((uint32_t)(tid + j * PC_L_PTPB), cnt - 1)];
     __syncthreads();
@@ -241,8 +246,12 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
     for (int j = 0; j < PC_L_PPPT; j++) {
         tag[j] = 0xFFFFFFFFu;
         if ((uint32_t)(tid + j * PC_L_PTPB) < cnt) {
-            const int b = pc_cell_index(LEVEL == 0 ? pt[j].x : pt[j].y);
-            if ((unsigned)b < 400u) tag[j] = (uint32_t)b | (atomicAdd(&hist[b], 1u) << 10);
+            if (LEVEL == 0) {
+                const int cy = pc_cell_index(pt[j].y);
+                yc[j] = (unsigned)cy < 400u ? (uint32_t)cy : 0xFFFFu;
+            }
+            const uint32_t b = (uint32_t)pc_cell_index(LEVEL == 0 ? pt[j].x : pt[j].y);
+            if (b < 400u) tag[j] = b | (atomicAdd(&hist[b], 1u) << 10);
         }
     }
     __syncthreads();
@@ -279,6 +288,7 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
             buf[3 * pos + 1] = pt[j].y;
             buf[3 * pos + 2] = pt[j].z;
             bin_of[pos] = (uint16_t)b;
+            if (LEVEL == 0) ycell_of[pos] = (uint16_t)yc[j];
         }
     }
     __syncthreads();
@@ -289,6 +299,8 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
         const uint32_t slot = delta[bin_of[e]] + e;
         dst[3 * (uint64_t)slot + (d - 3u * e)] = buf[d];
     }
+    if (LEVEL == 0)
+        for (uint32_t e = tid; e < kept; e += PC_L_PTPB) ycell[delta[bin_of[e]] + e] = ycell_of[e];
 }
 
 // ---- L7: one wave sorts one pencil by z cell and writes its table slice --------

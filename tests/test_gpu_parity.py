@@ -53,23 +53,29 @@ def test_cell_keys_match_reference_formula(psa, stages, torch_mod, oracle, golde
     assert int(stages.status.item()) == 0
 
 
-def test_predicate_on_golden_pairs(psa, stages, torch_mod, golden_dir):
-    """Each near-threshold pair is counted as its own 2-point problem: the HIP
-    predicate must agree with the reference's dist2()<=0.0025 on every one."""
+def test_cell_index_shortcut_is_exact_on_every_float(psa, torch_mod):
+    """The kernels' binary32 shortcut for the cell index against the reference's
+    binary64 expression (main.c:134-136), over all 2^32 float bit patterns."""
+    import ctypes
+    bad = torch_mod.zeros(1, dtype=torch_mod.int64, device="cuda:0")
+    rc = psa.lib().pc_selfcheck_cell_index_device(ctypes.c_void_p(bad.data_ptr()),
+                                                  ctypes.c_void_p(torch_mod.cuda.current_stream().cuda_stream))
+    assert rc == 0, psa.lib().pc_last_error()
+    torch_mod.cuda.synchronize()
+    assert int(bad.item()) == 0
+
+
+def test_predicate_on_golden_pairs(psa, stages, torch_mod, oracle, golden_dir):
+    """Near-threshold pairs from the reference's dist2()<=0.0025 (main.c:85-91,165):
+    all 8192 points at once against the oracle, then the exact-threshold cases one
+    pair per launch against the reference's own verdict."""
     z = np.load(os.path.join(golden_dir, "dist2_pairs.npz"))
     a, b, within = z["a"][:, :3], z["b"][:, :3], z["within"]
-    # put pair i alone in its own region so pairs cannot interact: shift by cell-aligned offsets is not
-    # bit-preserving, so instead count pairs one batch at a time where batches are far apart already
-    got = np.zeros(len(a), dtype=np.int64)
-    order = np.argsort(a[:, 0])
-    # points were drawn uniformly in a 19.8-wide box: 4096 pairs rarely touch, verify and mask those that do
-    for variant in VARIANTS:
-        total, _, _ = gpu_count(psa, stages, torch_mod, np.concatenate([a, b]), bin_v=variant[0], count_v=variant[1])
-        # expected total = pairs within threshold among all 8192 points (oracle on the same set)
-        import oracle_lib
-        want_total = oracle_lib.Oracle().count_pairs(np.concatenate([a, b]))[0]
-        assert total == want_total
-    # and one by one for the exact-threshold cases (two points per launch)
+    both = np.concatenate([a, b])
+    want_total = oracle.count_pairs(both)[0]
+    for bv, cv in VARIANTS:
+        total, _, _ = gpu_count(psa, stages, torch_mod, both, bin_v=bv, count_v=cv)
+        assert total == want_total, (bv, cv)
     idx = np.concatenate([np.arange(0, 64), np.arange(len(a) - 64, len(a))])
     for i in idx:
         c, _, _ = gpu_count(psa, stages, torch_mod, np.stack([a[i], b[i]]))
