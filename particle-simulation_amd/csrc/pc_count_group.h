@@ -97,6 +97,21 @@ __device__ __forceinline__ uint32_t pc_lds_addr(const void *p)
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
 }
 
+// Cross-lane reads that stay off the LDS crossbar: a wave-uniform lane index is a
+// v_readlane (the result is scalar), a neighbour's value is a DPP wave shift.
+__device__ __forceinline__ uint32_t pc_lane_value(uint32_t v, int uniform_lane)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(uniform_lane));
+}
+__device__ __forceinline__ uint32_t pc_from_lane_below(uint32_t v)      // lane t gets lane t-1's value, lane 0 gets 0
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t pc_from_lane_above(uint32_t v)      // lane t gets lane t+1's value, lane 63 gets 0
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+
 // Candidate-parallel test of the nh home particles staged in LDS.  A group of G
 // lanes takes one home particle, so the wave handles 64/G of them per step; lane
 // j of a group tests the candidate pairs (lo + 2j + 2G*c, +1), c = 0..NP-1, i.e.
@@ -105,14 +120,14 @@ __device__ __forceinline__ uint32_t pc_lds_addr(const void *p)
 // are padded with a never-matching point), so a pair is one aligned 8-byte LDS
 // read and is live or dead as a whole.
 template <int G, int NP>
-__device__ __forceinline__ uint32_t pc_g_steps(const pc_group_lds &L, uint32_t nh, int lane)
+__device__ __forceinline__ uint32_t pc_g_steps(const pc_group_lds &L, uint32_t h_first, uint32_t nh, int lane)
 {
     constexpr int NP0 = G >= 4 ? 1 : 4 / G;             // same-pencil pairs per lane: at least 8 candidates per group
     uint32_t hits = 0;
     const uint32_t j = lane & (G - 1), grp = lane / G;
-    nh = __builtin_amdgcn_readfirstlane(nh);             // wave-uniform: keep the step loop scalar
+    nh = __builtin_amdgcn_readfirstlane(nh);             // home particles h_first .. nh-1; wave-uniform: keep the step loop scalar
     const uint32_t ax_lds = pc_lds_addr(L.x);
-    for (uint32_t base = 0; base < nh; base += 64 / G) {
+    for (uint32_t base = __builtin_amdgcn_readfirstlane(h_first); base < nh; base += 64 / G) {
         const uint32_t hp = min(base + grp, nh - 1);
         const uint2 m = L.meta[hp];
         const float hx = L.hx[hp], hy = L.hy[hp], hz = L.hz[hp];
@@ -168,6 +183,27 @@ __device__ __forceinline__ uint32_t pc_g_steps(const pc_group_lds &L, uint32_t n
         }
     }
     return hits;    // wave-uniform (every lane holds the wave total)
+}
+
+// All home particles of a window with 2*G*NP candidates per home particle and
+// pass.  Whole steps of 64/G home particles use the narrowest groups; a last
+// step that would be less than half (quarter) full is run with groups twice (four
+// times) as wide and as many fewer pairs per lane: the same candidates per pass
+// at half (a quarter of) the instructions.
+template <int G, int NP>
+__device__ __forceinline__ uint32_t pc_g_window(const pc_group_lds &L, uint32_t nh, int lane)
+{
+    constexpr uint32_t H = 64 / G;
+    nh = __builtin_amdgcn_readfirstlane(nh);
+    if constexpr (NP >= 4 && G <= 8) {
+        const uint32_t rest = nh % H, whole = nh - rest;
+        uint32_t hits = pc_g_steps<G, NP>(L, 0, rest > H / 2 ? nh : whole, lane);
+        if (rest != 0 && rest <= H / 4) hits += pc_g_steps<4 * G, NP / 4>(L, whole, nh, lane);
+        else if (rest != 0 && rest <= H / 2) hits += pc_g_steps<2 * G, NP / 2>(L, whole, nh, lane);
+        return hits;
+    } else {
+        return pc_g_steps<G, NP>(L, 0, nh, lane);
+    }
 }
 
 // Candidate-stationary form for dense data: the wave keeps 256 merged candidates
@@ -261,9 +297,9 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
         uint32_t a0[5], a1[5];
 #pragma unroll
         for (int r = 0; r < 5; r++) {
-            const int c = min(lane, PC_NBB - 1);
-            a0[r] = T[tb[r] + c];
-            a1[r] = T[tb[r] + c + 1];
+            const uint32_t *e = T + (tb[r] + (uint32_t)min(lane, PC_NBB - 1));
+            a0[r] = e[0];
+            a1[r] = e[1];
         }
         while (done != home_hi && z0 < PC_NLAYERS) {
             const int zl = z0 > 0 ? z0 - 1 : 0;
@@ -291,21 +327,22 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                 const int c = min(zl2 + lane, PC_NBB - 1);
 #pragma unroll
                 for (int r = 0; r < 5; r++) {
-                    a0[r] = T[tb[r] + c];
-                    a1[r] = T[tb[r] + c + 1];
+                    const uint32_t *e = T + (tb[r] + (uint32_t)c);
+                    a0[r] = e[0];
+                    a1[r] = e[1];
                 }
             }
 
             if (fits) {
-                const uint32_t tot_m = __shfl(cum_m, t_last, 64);
-                const uint32_t tot_h = __shfl(cum_h, t_last, 64);          // row-0 points staged (home cells + cell above)
-                const uint32_t nh = __shfl(cum_h, t_last - 1, 64);         // home particles in this window
-                const uint32_t h_first = __shfl(s[0], th0, 64);            // global slot of the first staged row-0 point
+                const uint32_t tot_m = pc_lane_value(cum_m, t_last);
+                const uint32_t tot_h = pc_lane_value(cum_h, t_last);       // row-0 points staged (home cells + cell above)
+                const uint32_t nh = pc_lane_value(cum_h, t_last - 1);      // home particles in this window
+                const uint32_t h_first = pc_lane_value(s[0], th0);         // global slot of the first staged row-0 point
                 const uint32_t ex_m = cum_m - nm, ex_h = cum_h - n[0];
-                const uint32_t lo_m = __shfl_up(ex_m, 1, 64);              // start of cell t-1 in the merged array
-                const uint32_t hi_m = __shfl_down(cum_m, 1, 64);           // end of cell t+1
-                const uint32_t hi_h = __shfl_down(cum_h, 1, 64);           // end of cell t+1 in h[]
-                done = __shfl(s[0], t_last, 64);                           // start of the last window cell = next first home cell
+                const uint32_t lo_m = pc_from_lane_below(ex_m);            // start of cell t-1 in the merged array (0 for t = 0)
+                const uint32_t hi_m = pc_from_lane_above(cum_m);           // end of cell t+1
+                const uint32_t hi_h = pc_from_lane_above(cum_h);           // end of cell t+1 in the row-0 arrays
+                done = pc_lane_value(s[0], t_last);                        // start of the last window cell = next first home cell
                 if (nh != 0) {
                     // ---- merged copy of rows 1-4, in two stages.  Stage 1, lane t = cell t:
                     //      write the sorted-array slot of each of the cell's points to the
@@ -339,8 +376,7 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                     }
                     // ---- per home particle: its merged candidate range and the end of its row-0 range
                     if (lane >= th0 && lane < t_last) {
-                        const uint32_t lo = lane > 0 ? lo_m : 0u;
-                        for (uint32_t u = 0; u < n[0]; u++) L.meta[ex_h + u] = make_uint2(lo | (hi_m << 16), hi_h);
+                        for (uint32_t u = 0; u < n[0]; u++) L.meta[ex_h + u] = make_uint2(lo_m | (hi_m << 16), hi_h);
                     }
                     pc_dma_wait();
                     if (lane <= t_last && (nm_pts & 1)) L.x[ex_m + nm_pts] = __builtin_nanf("");   // ... and then never matches
@@ -348,20 +384,21 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                     // ---- rows 1-4: candidate-parallel steps, group size from the mean range length
                     // candidates per pass (2*G*NP) should cover mean + 2 sigma of a Poisson range length:
                     // m + 2*sqrt(m) + 1 <= 8, 16, 32, 64, 128  <=>  m <= 3, 9, 22, 49, 106
-                    const uint32_t mean3 = 3u * tot_m / (uint32_t)(t_last + 1);
+                    // (mean = 3 * tot_m / cells, compared without dividing)
+                    const uint32_t m3 = 3u * tot_m, cells = (uint32_t)(t_last + 1);
                     uint32_t hits;
-                    if (mean3 <= 3) hits = pc_g_steps<2, 2>(L, nh, lane);
-                    else if (mean3 <= 9) hits = pc_g_steps<2, 4>(L, nh, lane);
-                    else if (mean3 <= 22) hits = pc_g_steps<2, 8>(L, nh, lane);
-                    else if (mean3 <= 49) hits = pc_g_steps<4, 8>(L, nh, lane);
-                    else if (mean3 <= 106) hits = pc_g_steps<8, 8>(L, nh, lane);
+                    if (m3 < 4 * cells) hits = pc_g_window<2, 2>(L, nh, lane);
+                    else if (m3 < 10 * cells) hits = pc_g_window<2, 4>(L, nh, lane);
+                    else if (m3 < 23 * cells) hits = pc_g_window<2, 8>(L, nh, lane);
+                    else if (m3 < 50 * cells) hits = pc_g_window<4, 8>(L, nh, lane);
+                    else if (m3 < 107 * cells) hits = pc_g_window<8, 8>(L, nh, lane);
                     else {
                         // dense window: per home cell, candidates stay in registers while the
                         // cell's home particles stream by
                         hits = 0;
                         for (int t = th0; t < t_last; t++) {
-                            const uint32_t c_lo = t > 0 ? __shfl(lo_m, t, 64) : 0u, c_hi = __shfl(hi_m, t, 64);
-                            const uint32_t hb = __shfl(ex_h, t, 64), he = hb + __shfl(n[0], t, 64);
+                            const uint32_t c_lo = pc_lane_value(lo_m, t), c_hi = pc_lane_value(hi_m, t);
+                            const uint32_t hb = pc_lane_value(ex_h, t), he = hb + pc_lane_value(n[0], t);
                             hits += pc_g_block<false>(L, c_lo, c_hi, hb, he, lane);
                         }
                         // same pencil (the steps above count these themselves): lane per home particle
@@ -380,15 +417,15 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
             } else {
                 // ---- home cell z0 with its neighbours does not fit: stream the
                 //      candidate ranges through LDS in pieces ---------------------
-                const uint32_t h0 = __shfl(s[0], th0, 64);
-                const uint32_t h1 = h0 + __shfl(n[0], th0, 64);
+                const uint32_t h0 = pc_lane_value(s[0], th0);
+                const uint32_t h1 = h0 + pc_lane_value(n[0], th0);
                 uint32_t c_lo[5], c_hi[5];
 #pragma unroll
                 for (int r = 0; r < 5; r++) {
                     // rows 1-4: cells z0-1..z0+1 ; row 0: cells z0 (later slots) and z0+1
-                    c_lo[r] = r == 0 ? h0 : __shfl(s[r], 0, 64);
+                    c_lo[r] = r == 0 ? h0 : pc_lane_value(s[r], 0);
                     const int te = min(th0 + 1, 63);
-                    c_hi[r] = __shfl(s[r], te, 64) + __shfl(n[r], te, 64);
+                    c_hi[r] = pc_lane_value(s[r], te) + pc_lane_value(n[r], te);
                 }
 #pragma unroll
                 for (int r = 0; r < 5; r++) {
