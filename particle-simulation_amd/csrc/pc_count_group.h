@@ -38,10 +38,17 @@ struct pc_f3 { float x, y, z; };          // one point as stored in the sorted a
 
 struct alignas(16) pc_group_lds {
     float x[PC_G_CAPM], y[PC_G_CAPM], z[PC_G_CAPM];   // merged rows 1-4 (reads may run past the end into the next arrays)
-    float hx[PC_G_CAPH], hy[PC_G_CAPH], hz[PC_G_CAPH]; // row 0: home cells and the cell above
-    uint2 meta[PC_G_CAPH];                             // per home particle: .x = lo | hi<<16 (merged range), .y = end of its row-0 range
-    uint32_t src[PC_G_CAPM];                           // sorted-array slot of every merged candidate (gather list of the copy)
+    union {
+        struct {
+            float hx[PC_G_CAPH], hy[PC_G_CAPH], hz[PC_G_CAPH]; // row 0: home cells and the cell above
+            uint2 meta[PC_G_CAPH];                             // per home particle: .x = lo | hi<<16 (merged range), .y = end of its row-0 range
+        };
+        // sorted-array slot of every merged candidate (gather list of the copy); dead once
+        // the merged copy has been issued, which is before the row-0 data is written
+        uint32_t src[PC_G_CAPM];
+    };
 };
+static_assert(sizeof(uint32_t) * PC_G_CAPM <= (3 * sizeof(float) + sizeof(uint2)) * PC_G_CAPH, "the gather list must fit under the row-0 arrays");
 
 // Asynchronous copy of one dword per lane from global memory into LDS: lane t's
 // dword lands at lds_chunk[t].  The source address is per lane, the destination
@@ -250,7 +257,7 @@ __device__ __forceinline__ uint32_t pc_g_block(const pc_group_lds &L, uint32_t c
     return hits;
 }
 
-__global__ void __launch_bounds__(PC_G_WAVES * 64, 4)   // 4 waves per SIMD: LDS admits 4 workgroups per CU
+__global__ void __launch_bounds__(PC_G_WAVES * 64, 4)   // 4 waves per SIMD (a fifth would fit the LDS but spills registers)
 pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T, int x_lo, int x_hi,
                    unsigned int *__restrict__ queue, unsigned long long *__restrict__ out)
 {
@@ -366,6 +373,8 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                         const uint32_t src = q < tot_m ? L.src[q] : home_lo;
                         pc_dma_point(pts + 3 * (uint64_t)src, L.x + q0, L.y + q0, L.z + q0);
                     }
+                    // (every lane has consumed its gather-list entries by now -- they were the DMA
+                    // addresses -- so the list's space can take the row-0 data)
                     // ---- row 0: one contiguous run of at most PC_G_CAPH points
 #pragma unroll
                     for (int qq = 0; qq < PC_G_CAPH / 64; qq++) {
