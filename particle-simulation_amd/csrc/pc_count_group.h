@@ -7,21 +7,24 @@
 // (i+1,j+1) -- "rows 1-4" -- plus cell k+1 of the home pencil ("row 0").
 //
 // The wave walks its pencil in windows of up to 64 z cells, lane t owning cell
-// t of the window for all bookkeeping (table reads, prefix sums, copies).  The
-// points of rows 1-4 are copied to LDS MERGED CELL-MAJOR (cell t's points of all
-// four rows are adjacent), so the candidates of a home particle in cell k are
-// ONE contiguous LDS range: cells k-1..k+1 of the merged array.  A group of G
-// lanes then takes one home particle and the group's lanes take 4 candidates
-// each (two packed pairs: v_pk_add/mul_f32), so a wave tests 64/G home particles
-// per step with no per-lane loops and no divergence; G is picked per window from
-// the mean range length.  Same-pencil pairs (later points of the cell, and cell
-// k+1 of row 0: main.c:215-221 and offset (0,0,1)) are few and are counted by a
-// short lane-per-home-particle loop.  A home cell whose candidates do not fit
-// the LDS buffer is counted against buffer-sized pieces of its candidate ranges.
+// t of the window for all bookkeeping (table reads, prefix sums, the gather
+// list).  The points of rows 1-4 are copied to LDS MERGED CELL-MAJOR (cell t's
+// points of all four rows are adjacent, padded to an even count), so the
+// candidates of a home particle in cell k are ONE contiguous LDS range: cells
+// k-1..k+1 of the merged array.  The copy itself is a gather through LDS-DMA
+// loads (global memory -> LDS without passing registers).  A group of G lanes
+// then takes one home particle and each lane NP pairs of candidates (one 8-byte
+// LDS read per pair and coordinate, v_pk_add/mul_f32 on both at once), so a wave
+// tests 64/G home particles per step with no per-lane loops and no divergence;
+// (G, NP) is picked per window from the mean range length.  Same-pencil pairs
+// (later points of the cell, and cell k+1 of row 0: main.c:215-221 and offset
+// (0,0,1)) are a second short range of the same step.  A home cell whose
+// candidates do not fit the LDS buffer is counted against buffer-sized pieces of
+// its candidate ranges.
 //
 // Hit counts come from compare masks (ballot + popcount on the scalar unit);
-// one 64-bit atomic per workgroup.  Workgroup -> pencil mapping is XCD-aware as
-// in variant 2 (speed only).
+// one 64-bit atomic per workgroup.  Waves are persistent and draw pencils from a
+// work counter per XCD group (speed only).
 #pragma once
 #include <utility>
 #include "pc_device.h"
@@ -34,7 +37,6 @@
 #define PC_G_WG_PER_BAND ((PC_G_BAND + PC_G_WAVES - 1) / PC_G_WAVES)
 
 typedef float pc_v2f __attribute__((ext_vector_type(2)));
-struct pc_f3 { float x, y, z; };          // one point as stored in the sorted array (12 bytes, 4-byte aligned)
 
 struct alignas(16) pc_group_lds {
     float x[PC_G_CAPM], y[PC_G_CAPM], z[PC_G_CAPM];   // merged rows 1-4 (reads may run past the end into the next arrays)

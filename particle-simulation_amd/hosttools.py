@@ -103,8 +103,3 @@ def filter_slab(xyz, x_lo, x_hi):
     out = np.empty_like(xyz)
     n = lib().xyz_filter_slab(xyz.ctypes.data, xyz.shape[0], x_lo, x_hi, out.ctypes.data)
     return out[:n].copy()
-
-
-def slab_cuts(n_ranks, layers=400):
-    """Equal-width x-slab boundaries [c0..cN]: rank r owns home layers [c[r], c[r+1])."""
-    return [layers * r // n_ranks for r in range(n_ranks + 1)]

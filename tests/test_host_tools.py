@@ -1,5 +1,6 @@
 """CPU: the product's host code (tokenizer, generator, slab router, CLI surface)
 against the golden vectors and the oracle."""
+import importlib
 import json
 import os
 import subprocess
@@ -73,8 +74,9 @@ def test_slab_router_and_cuts(ht, oracle):
     import oracle_lib
     xyz = ht.generate(ht.UNIFORM, 5, 100000)
     keys = oracle.cell_keys(xyz)
+    sharding = importlib.import_module("particle_simulation_amd.sharding")
     for n in (1, 2, 3, 8):
-        cuts = ht.slab_cuts(n)
+        cuts = sharding.equal_cuts(n)
         assert cuts[0] == 0 and cuts[-1] == 400 and all(b > a for a, b in zip(cuts, cuts[1:]))
     for lo, hi in ((0, 50), (150, 200), (350, 400)):
         got = ht.filter_slab(xyz, lo, hi)
