@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks "
                          "(ranks share devices, the 8-byte sum goes through host memory)")
+    ap.add_argument("--as-rank", type=int, nargs=2, metavar=("R", "W"), default=None,
+                    help="single process, no collective: time the slab that rank R of a W-rank run would hold "
+                         "(a per-rank preview of the N-GPU line on a one-GPU box; not a bench result)")
     args = ap.parse_args()
 
     import numpy as np
@@ -105,14 +108,18 @@ def main():
     total_points = args.points or (base_points * world if scaling == "weak" else base_points)
     kind = ht.UNIFORM if kind_name == "uniform" else ht.BLOBS
     sh = importlib.import_module("particle_simulation_amd.sharding")
-    if world > 1 and kind_name == "blobs":
+    slabs, slab = world, rank                    # how many x slabs the domain is cut into, and which one is ours
+    if args.as_rank and world == 1:
+        slab, slabs = args.as_rank
+        total_points = args.points or (base_points * slabs if scaling == "weak" else base_points)
+    if slabs > 1 and kind_name == "blobs":
         # clustered input: cut where the estimated pair-test cost (layer population squared) balances
         pop = ht.layer_histogram(kind, args.seed, total_points, sigma,
                                  threads=max(1, ht.host_threads() // min(world, 8))).astype(np.float64)
-        cuts = sh.balanced_cuts(pop * pop, world)
+        cuts = sh.balanced_cuts(pop * pop, slabs)
     else:
-        cuts = sh.equal_cuts(world)
-    x_lo, x_hi = cuts[rank], cuts[rank + 1]
+        cuts = sh.equal_cuts(slabs)
+    x_lo, x_hi = cuts[slab], cuts[slab + 1]
     if args.bin_variant is not None:
         psa.set_variant("bin", args.bin_variant)
     if args.count_variant is not None:
@@ -121,7 +128,7 @@ def main():
     # ---- synthetic input: this rank's slab plus its +x halo layer, resident in HBM ----
     t_gen = time.time()
     threads = max(1, ht.host_threads() // min(world, 8)) if world > 1 else ht.host_threads()
-    if world == 1:
+    if slabs == 1:
         host = ht.generate(kind, args.seed, total_points, sigma, threads=threads)
     else:
         host = ht.generate(kind, args.seed, total_points, sigma, x_lo=x_lo, x_hi=min(x_hi, 399), threads=threads)
@@ -134,8 +141,7 @@ def main():
     total = torch.zeros(1, dtype=torch.int64, device=red_device)
 
     def step():
-        st.bin(xyz)
-        st.count_sorted(n, x_lo, x_hi)
+        st.count_pairs(xyz, x_lo, x_hi)          # keys + binning + pair test, one C-ABI call
         if world > 1:
             total.copy_(st.result[0:1])      # (gloo rehearsal: a synchronising copy to host)
             dist.all_reduce(total)           # the path's only collective: one 8-byte sum
@@ -212,10 +218,11 @@ def main():
             "value": tests / (elapsed / args.steps),
             "unit": "pairs-tested/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            **({"preview_of_rank": args.as_rank} if args.as_rank and world == 1 else {}),
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "points": total_points, "points_held_incl_halo": points_held,
-                       "cutoff": 0.05, "slabs": world, "slab_cuts": cuts, "seed": args.seed,
+                       "cutoff": 0.05, "slabs": slabs, "slab_cuts": cuts, "seed": args.seed,
                        "generator_s": round(t_gen, 2)},
             "pairs": pairs, "tests": tests,
             "pairs_tested_per_s_pair_test_kernel_only": (tests_local / (cnt_ms * 1e-3)) if cnt_ms else None,
@@ -227,7 +234,7 @@ def main():
             "kernels": kernels,
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.as_rank:
             out["cpu_baseline"] = cpu_baseline(psa, ht, st, torch, kind, args.seed, total_points, sigma, device)
         print(json.dumps(out))
     if world > 1:

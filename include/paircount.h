@@ -127,8 +127,11 @@ int pc_count_tests_device(const uint32_t *d_cell_start, int x_lo, int x_hi,
                           uint64_t *d_ntests, void *stream);
 
 /* Whole hot path on device-resident input: keys, binning, pair test.
-   d_sorted_xyz / d_cell_start as above (outputs, kept for inspection);
-   *d_npairs is overwritten with the count. */
+   d_sorted_xyz / d_cell_start as above (outputs, kept for inspection), except
+   that they are complete only for the x layers x_lo .. x_hi (the slab and its
+   halo layer, all the pair test reads; with x_hi = 400 also the two empty
+   padding layers, i.e. to the end of the table); *d_npairs is overwritten with
+   the count. */
 int pc_count_pairs_device(const float *d_xyz, uint64_t n, int x_lo, int x_hi,
                           float *d_sorted_xyz, uint32_t *d_cell_start,
                           void *d_workspace, size_t workspace_bytes,

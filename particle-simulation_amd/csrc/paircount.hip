@@ -183,8 +183,9 @@ static pc_lds_ws carve_lds_ws(void *ws, uint64_t n)
     return w;
 }
 
+// layers [layer_lo, layer_hi] get their pencils sorted and their table slices written (all: 0 .. PC_NBB-1)
 static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *table, void *ws,
-                   int32_t *d_status, hipStream_t s)
+                   int32_t *d_status, hipStream_t s, int layer_lo, int layer_hi)
 {
     pc_lds_ws w = carve_lds_ws(ws, n);
     PC_HIP(hipMemsetAsync(w.layer_count, 0, (PC_L_NREP * PC_L_BINS + PC_L_NREP * PC_L_PSTRIDE) * sizeof(uint32_t), s));
@@ -204,8 +205,9 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
     if (n)
         PC_LAUNCH("pc_l6_partition_y", pc_l36_partition<1>, dim3(tiles + PC_NBB), dim3(PC_L_PTPB), s, d_sorted, n,
                   w.tmp, w.layer_start, w.layer_tile, w.tile_layer, w.pencil_cursor, w.ycell);
-    PC_LAUNCH("pc_l7_sort_pencils", pc_l7_sort_pencils, dim3((PC_L_NPENCILS + PC_L7_WAVES - 1) / PC_L7_WAVES),
-              dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted, w.pencil_start, table, d_status);
+    const uint32_t first_pencil = (uint32_t)layer_lo * PC_NBB, end_pencil = (uint32_t)(layer_hi + 1) * PC_NBB;
+    PC_LAUNCH("pc_l7_sort_pencils", pc_l7_sort_pencils, dim3((end_pencil - first_pencil + PC_L7_WAVES - 1) / PC_L7_WAVES),
+              dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted, w.pencil_start, table, first_pencil, end_pencil, d_status);
     PC_HIP(hipGetLastError());
     return PC_OK;
 }
@@ -240,9 +242,23 @@ extern "C" int pc_cell_keys_device(const float *d_xyz, uint64_t n, uint32_t *d_k
     return PC_OK;
 }
 
+static int bin_layers(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
+                      uint32_t *d_cell_start, void *d_workspace, size_t workspace_bytes,
+                      int32_t *d_status, void *stream, int layer_lo, int layer_hi);
+
 extern "C" int pc_bin_device(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
                              uint32_t *d_cell_start, void *d_workspace, size_t workspace_bytes,
                              int32_t *d_status, void *stream)
+{
+    return bin_layers(d_xyz, n, d_sorted_xyz, d_cell_start, d_workspace, workspace_bytes, d_status, stream, 0, PC_NBB - 1);
+}
+
+// Binning whose result is complete for the layers [layer_lo, layer_hi] only (the
+// default variant skips the final per-pencil sort and the table slices of the
+// other layers; a slab's pair test never reads them).
+static int bin_layers(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
+                      uint32_t *d_cell_start, void *d_workspace, size_t workspace_bytes,
+                      int32_t *d_status, void *stream, int layer_lo, int layer_hi)
 {
     if (!d_cell_start || !d_status || !d_workspace)
         return pc_fail(PC_ERR_ARG, "pc_bin_device: null pointer");
@@ -252,7 +268,7 @@ extern "C" int pc_bin_device(const float *d_xyz, uint64_t n, float *d_sorted_xyz
         return pc_fail(PC_ERR_ARG, "pc_bin_device: workspace %zu < %zu bytes", workspace_bytes,
                        pc_workspace_bytes(n));
     hipStream_t s = (hipStream_t)stream;
-    if (g_variant_bin == 1) return bin_lds(d_xyz, n, d_sorted_xyz, d_cell_start, d_workspace, d_status, s);
+    if (g_variant_bin == 1) return bin_lds(d_xyz, n, d_sorted_xyz, d_cell_start, d_workspace, d_status, s, layer_lo, layer_hi);
     const uint64_t m = PC_NCELLS + 2;
     uint32_t *keys = (uint32_t *)d_workspace;
     uint32_t *sums = (uint32_t *)((char *)d_workspace + align_up((size_t)n * 4 + 4, 256));
@@ -369,7 +385,9 @@ extern "C" int pc_count_pairs_device(const float *d_xyz, uint64_t n, int x_lo, i
     if (!d_npairs) return pc_fail(PC_ERR_ARG, "pc_count_pairs_device: null result pointer");
     int rc = check_slab("pc_count_pairs_device", x_lo, x_hi);
     if (rc) return rc;
-    rc = pc_bin_device(d_xyz, n, d_sorted_xyz, d_cell_start, d_workspace, workspace_bytes, d_status, stream);
+    // home layers [x_lo, x_hi) and the halo layer x_hi are all the pair test reads
+    rc = bin_layers(d_xyz, n, d_sorted_xyz, d_cell_start, d_workspace, workspace_bytes, d_status, stream, x_lo,
+                    x_hi < PC_NLAYERS ? x_hi : PC_NBB - 1);        // the last slab also gets the empty padding layers
     if (rc) return rc;
     PC_HIP(hipMemsetAsync(d_npairs, 0, sizeof(uint64_t), (hipStream_t)stream));
     return pc_count_sorted_device(d_sorted_xyz, d_cell_start, n, x_lo, x_hi, d_npairs, stream);
@@ -554,7 +572,8 @@ extern "C" int pc_finish(pc_context *c, int64_t *npairs)
     PC_HIP(hipMemsetAsync(b.res, 0, 16, s));
     PC_HIP(hipMemsetAsync(b.status, 0, 4, s));
     PC_HIP(hipEventRecord(b.ev[0], s));
-    int rc = pc_bin_device(c->d_xyz, n, b.sorted, b.table, b.ws, wsb, b.status, s);
+    int rc = bin_layers(c->d_xyz, n, b.sorted, b.table, b.ws, wsb, b.status, s, c->x_lo,
+                        c->x_hi < PC_NLAYERS ? c->x_hi : PC_NBB - 1);
     if (rc) return rc;
     PC_HIP(hipEventRecord(b.ev[1], s));
     rc = pc_count_sorted_device(b.sorted, b.table, n, c->x_lo, c->x_hi, b.res, s);

@@ -334,14 +334,15 @@ __device__ __forceinline__ void pc_l7_scan_bins(uint32_t *hist, int lane)
 __global__ void __launch_bounds__(PC_L7_WAVES * 64)
 pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
                    const uint32_t *__restrict__ pencil_start, uint32_t *__restrict__ table,
-                   int32_t *__restrict__ status)
+                   uint32_t first_pencil, uint32_t end_pencil, int32_t *__restrict__ status)
 {
     __shared__ uint32_t hist_all[PC_L7_WAVES][PC_L_BINS];
     __shared__ __attribute__((aligned(16))) float stage_all[PC_L7_WAVES][PC_L7_CAP * 3 + 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t *hist = hist_all[wave];
-    const uint32_t pencil = blockIdx.x * PC_L7_WAVES + wave;
-    if (pencil >= PC_L_NPENCILS) return;
+    // pencils [first_pencil, end_pencil): all of them, or the layers one slab's pair test reads
+    const uint32_t pencil = first_pencil + blockIdx.x * PC_L7_WAVES + wave;
+    if (pencil >= end_pencil) return;
     const uint32_t base = pencil_start[pencil], n = pencil_start[pencil + 1] - base;
     uint32_t *slice = table + (uint64_t)pencil * PC_NBB;
     if (pencil == PC_L_NPENCILS - 1 && lane < 2) table[(uint64_t)PC_L_NPENCILS * PC_NBB + lane] = base + n;
