@@ -274,16 +274,23 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
     // (layer-major) from the group's counter, so neighbouring pencils are in flight
     // together and a wave that finishes a light pencil simply draws the next one.
     // The next index is drawn before the current pencil is processed (its latency
-    // is hidden); every wave leaves the loop when its draw passes the end.
-    const int g = blockIdx.x & 7;
+    // is hidden).  When its own band is used up a wave moves on to the next
+    // group's band (clustered inputs load the bands unevenly); it leaves the loop
+    // once it has seen all eight counters past the end.
+    int g = blockIdx.x & 7, bands_done = 0;
     const int band_pencils = (x_hi - x_lo) * PC_G_BAND;
-    unsigned int *q = queue + g * PC_G_QUEUE_STRIDE;
     int m = 0;
-    if (lane == 0) m = (int)atomicAdd(q, 1u);
+    if (lane == 0) m = (int)atomicAdd(queue + g * PC_G_QUEUE_STRIDE, 1u);
     m = __builtin_amdgcn_readfirstlane(m);
-    while (m < band_pencils) {
+    for (;;) {
+        while (m >= band_pencils && ++bands_done < 8) {
+            g = (g + 1) & 7;
+            if (lane == 0) m = (int)atomicAdd(queue + g * PC_G_QUEUE_STRIDE, 1u);
+            m = __builtin_amdgcn_readfirstlane(m);
+        }
+        if (m >= band_pencils) break;
         int m_next = 0;
-        if (lane == 0) m_next = (int)atomicAdd(q, 1u);
+        if (lane == 0) m_next = (int)atomicAdd(queue + g * PC_G_QUEUE_STRIDE, 1u);
         const int layer = x_lo + m / PC_G_BAND;
         const int j = g * PC_G_BAND + m % PC_G_BAND;
         // table bases of the five rows; invalid rows (outside the occupied grid) are empty
