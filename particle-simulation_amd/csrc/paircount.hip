@@ -338,13 +338,23 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
         PC_LAUNCH("pc_c0_count_global", pc_c0_count_global, dim3(grid_for(n, 256, 1 << 20)), dim3(256), (hipStream_t)stream, d_sorted_xyz, d_cell_start, c_lo, c_hi,
                            (unsigned long long *)d_npairs);
     } else if (g_variant_count == 3) {
-        // persistent: 16 waves per CU (VGPR-limited residency), never more waves than pencils;
+        // persistent: one resident set of waves, never more waves than pencils;
         // the eight work counters are zeroed on the stream ahead of the launch
         unsigned int *queue = nullptr;
         int rc2 = count_queue(&queue);
         if (rc2) return rc2;
         PC_HIP(hipMemsetAsync(queue, 0, 8 * PC_G_QUEUE_STRIDE * sizeof(unsigned int), (hipStream_t)stream));
-        const int want = 256 * 16 / PC_G_WAVES, most = ((x_hi - x_lo) * PC_NLAYERS + PC_G_WAVES - 1) / PC_G_WAVES;
+        // as many workgroups as are resident at once (registers and LDS decide: asked of the runtime, once)
+        static int resident = 0;
+        if (!resident) {
+            int per_cu = 0, dev = 0;
+            hipDeviceProp_t prop;
+            PC_HIP(hipGetDevice(&dev));
+            PC_HIP(hipGetDeviceProperties(&prop, dev));
+            PC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pc_c3_count_groups, PC_G_WAVES * 64, 0));
+            resident = (per_cu > 0 ? per_cu : 16) * prop.multiProcessorCount;
+        }
+        const int want = resident, most = ((x_hi - x_lo) * PC_NLAYERS + PC_G_WAVES - 1) / PC_G_WAVES;
         const int grid = ((want < most ? want : most) + 7) / 8 * 8;
         PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
                   d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, (unsigned long long *)d_npairs);

@@ -133,6 +133,9 @@ __device__ __forceinline__ uint32_t pc_g_steps(const pc_group_lds &L, uint32_t h
 {
     constexpr int NP0 = G >= 4 ? 1 : 4 / G;             // same-pencil pairs per lane: at least 8 candidates per group
     uint32_t hits = 0;
+    // (the lane number is made opaque here so that the per-lane constants of each instantiation are
+    // recomputed per window instead of being kept in registers across the whole kernel)
+    asm volatile("" : "+v"(lane));
     const uint32_t j = lane & (G - 1), grp = lane / G;
     nh = __builtin_amdgcn_readfirstlane(nh);             // home particles h_first .. nh-1; wave-uniform: keep the step loop scalar
     const uint32_t ax_lds = pc_lds_addr(L.x);
