@@ -345,14 +345,17 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
         if (rc2) return rc2;
         PC_HIP(hipMemsetAsync(queue, 0, 8 * PC_G_QUEUE_STRIDE * sizeof(unsigned int), (hipStream_t)stream));
         // as many workgroups as are resident at once (registers and LDS decide: asked of the runtime, once)
-        static int resident = 0;
+        static int resident_on[64];               // per device ordinal (count_queue has checked the range)
+        int dev = 0;
+        PC_HIP(hipGetDevice(&dev));
+        int resident = resident_on[dev];
         if (!resident) {
-            int per_cu = 0, dev = 0;
+            int per_cu = 0;
             hipDeviceProp_t prop;
-            PC_HIP(hipGetDevice(&dev));
             PC_HIP(hipGetDeviceProperties(&prop, dev));
             PC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pc_c3_count_groups, PC_G_WAVES * 64, 0));
             resident = (per_cu > 0 ? per_cu : 16) * prop.multiProcessorCount;
+            resident_on[dev] = resident;
         }
         const int want = resident, most = ((x_hi - x_lo) * PC_NLAYERS + PC_G_WAVES - 1) / PC_G_WAVES;
         const int grid = ((want < most ? want : most) + 7) / 8 * 8;

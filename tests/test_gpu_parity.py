@@ -205,3 +205,46 @@ def test_full_size_properties(psa, torch_mod):
     a = st.pairs()
     st.count_pairs(srt[first_lo:].contiguous(), cut, 400)
     assert a + st.pairs() == whole
+
+
+def test_config3_size_properties(psa, torch_mod):
+    """100 M uniform points (the metric's configuration, same stream as bench.py):
+    no oracle run at this size, so the count is checked through properties --
+    the analytic expectation, permutation invariance, the table, and additivity
+    over four x slabs each holding only its own points plus the halo layer."""
+    import importlib
+    torch = torch_mod
+    ht = importlib.import_module("particle_simulation_amd.hosttools")
+    n = 100_000_000
+    host = ht.generate(ht.UNIFORM, 7, n)
+    xyz = torch.from_numpy(host).to("cuda:0")
+    del host
+    st = psa.DeviceStages(n, "cuda:0")
+    st.count_pairs(xyz)
+    st.count_tests()
+    whole, tests = st.pairs(), st.tests()
+    assert 3.2e8 < whole < 3.35e8 and 2.05e9 < tests < 2.15e9        # analytic expectation 3.27e8 / 2.1e9
+    table = st.table[: NBB ** 3 + 1]
+    assert int(table[-1].item()) == n
+    assert bool((table[1:] >= table[:-1]).all())
+    srt = st.sorted[:n].clone()
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(99)
+    perm = torch.randperm(n, device="cuda:0", generator=g)
+    shuffled = xyz[perm].contiguous()
+    del perm, xyz
+    st.count_pairs(shuffled)
+    assert st.pairs() == whole
+    del shuffled
+    # four slabs cut out of the sorted array (layers are contiguous runs): own layers + halo layer
+    table = st.table[: NBB ** 3 + 1].clone()
+    cuts = [0, 100, 200, 300, 400]
+    total = total_tests = 0
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        a = int(table[lo * NBB * NBB].item())
+        b = int(table[min(hi + 1, NBB) * NBB * NBB].item())
+        st.count_pairs(srt[a:b].contiguous(), lo, hi)
+        st.count_tests(lo, hi)
+        total += st.pairs()
+        total_tests += st.tests()
+    assert total == whole and total_tests == tests
