@@ -248,3 +248,39 @@ def test_config3_size_properties(psa, torch_mod):
         total += st.pairs()
         total_tests += st.tests()
     assert total == whole and total_tests == tests
+
+
+def _cell_box(rng, n, lo_cell, hi_cell):
+    """n points uniform inside the box of cells [lo_cell, hi_cell) (per axis), kept clear of the box faces."""
+    lo = np.asarray(lo_cell, np.float64) * 0.05 - 10.0 + 1e-4
+    hi = np.asarray(hi_cell, np.float64) * 0.05 - 10.0 - 1e-4
+    return rng.uniform(lo, hi, (n, 3))
+
+
+@pytest.mark.parametrize("shape", ["pencil", "two_pencils", "sheet", "gradient", "needle_in_dust", "layer_pair"])
+def test_density_regimes(psa, stages, torch_mod, oracle, shape):
+    """Inputs that drive the pair test through every window regime (sparse groups,
+    wide groups, dense windows, piece-wise streaming) and through the switches
+    between them inside one pencil."""
+    rng = np.random.default_rng(sum(shape.encode()))
+    if shape == "pencil":                  # one z pencil, ~100 points per cell
+        xyz = _cell_box(rng, 40_000, (200, 200, 0), (201, 201, 400))
+    elif shape == "two_pencils":           # neighbours in y: every point has dense row-1 candidates
+        xyz = _cell_box(rng, 60_000, (10, 399 - 1, 0), (11, 400, 400))
+    elif shape == "sheet":                 # one x layer: rows 2-4 are empty everywhere
+        xyz = _cell_box(rng, 200_000, (399, 0, 0), (400, 400, 400))
+    elif shape == "gradient":              # occupancy climbing from 0 to ~250 per cell along z
+        z = np.sqrt(rng.uniform(0, 1, 120_000)) * 19.9 - 9.95
+        xy = _cell_box(rng, 120_000, (100, 100, 0), (103, 103, 1))[:, :2]
+        xyz = np.column_stack([xy, z])
+    elif shape == "needle_in_dust":        # one cell with 5000 points inside sparse background
+        xyz = np.concatenate([rng.uniform(-9.999, 9.999, (150_000, 3)),
+                              _cell_box(rng, 5000, (57, 311, 123), (58, 312, 124))])
+    else:                                  # two adjacent x layers, moderately dense: all five rows populated
+        xyz = _cell_box(rng, 400_000, (250, 150, 150), (252, 250, 250))
+    xyz = xyz.astype(np.float32)
+    want, want_tests = oracle.count_pairs(xyz)
+    for bv, cv in VARIANTS:
+        got, tests, _ = gpu_count(psa, stages, torch_mod, xyz, bin_v=bv, count_v=cv)
+        assert got == want, (shape, bv, cv)
+        assert tests == want_tests
