@@ -267,28 +267,37 @@ def cpu_baseline(psa, ht, st, torch, kind, seed, total_points, sigma, device):
         sample_desc = "x-slab cells [%d,%d] of the workload stream: %d points, %d tests" % (lo, hi, npts, tests)
         ref_bin = os.path.join(ROOT, "oracle", "_ref", "main_timer")
         if os.path.exists(ref_bin):
-            t0 = time.time()
-            r = subprocess.run([ref_bin, "-f", path, "-p", str(cores), "-c", str(cores)],
-                               capture_output=True, text=True, timeout=900)
-            wall = time.time() - t0
-            if r.returncode != 0:
-                return {"error": "reference binary failed rc=%d: %s" % (r.returncode, r.stderr[-200:])}
+            # both programs: best of two runs (the first touch of a freshly written file is slow for either)
+            wall, r = None, None
+            for _ in range(2):
+                t0 = time.time()
+                rr = subprocess.run([ref_bin, "-f", path, "-p", str(cores), "-c", str(cores)],
+                                    capture_output=True, text=True, timeout=900)
+                w = time.time() - t0
+                if rr.returncode != 0:
+                    return {"error": "reference binary failed rc=%d: %s" % (rr.returncode, rr.stderr[-200:])}
+                if wall is None or w < wall:
+                    wall, r = w, rr
             phases = {m.group(1): int(m.group(2)) / 1e6 for m in re.finditer(r"(\w+):\s+(\d+) us", r.stdout)}
             count = int([ln for ln in r.stdout.splitlines() if ln.strip().isdigit()][-1])
             # the same file through the product's C host program (tokenize on the host, bin+count on the GPU)
             e2e = None
             main_bin = ht.MAIN_PATH
             if os.path.exists(main_bin):
-                t1 = time.time()
-                g = subprocess.run([main_bin, "-f", path, "-p", str(cores)], capture_output=True, text=True,
-                                   timeout=900, env=dict(os.environ, PAIRCOUNT_TIMER="1"))
-                gwall = time.time() - t1
+                gwall, g = None, None
+                for _ in range(2):
+                    t1 = time.time()
+                    gg = subprocess.run([main_bin, "-f", path, "-p", str(cores)], capture_output=True, text=True,
+                                        timeout=900, env=dict(os.environ, PAIRCOUNT_TIMER="1"))
+                    w = time.time() - t1
+                    if gwall is None or w < gwall or g.returncode != 0:
+                        gwall, g = w, gg
                 if g.returncode == 0:
                     gph = {m.group(1): float(m.group(2)) / 1e6 for m in re.finditer(r"(\w[\w()]*):\s+(\d+) us", g.stderr)}
                     e2e = {"file_bytes": os.path.getsize(path), "gpu_host_program_wall_s": gwall, "gpu_phases_s": gph,
                            "gpu_count": int(g.stdout.strip()), "reference_wall_s": wall,
-                           "note": "process start to count printed, same file; the GPU program's wall time includes HIP "
-                                   "start-up and a pageable-memory PCIe copy of the parsed points"}
+                           "note": "process start to count printed, same file, best of two runs each; the GPU program's "
+                                   "wall time includes HIP start-up and a pageable-memory PCIe copy of the parsed points"}
             return {"end_to_end": e2e, "value": tests / phases["count"], "unit": "pairs-tested/s", "cores": cores, "kind": "reference",
                     "sample": sample_desc, "phases_s": phases, "wall_s": wall, "pairs": count,
                     "matches_hip_count": count == gpu_pairs,
