@@ -218,12 +218,50 @@ __device__ __forceinline__ uint32_t pc_g_window(const pc_group_lds &L, uint32_t 
     }
 }
 
-// Candidate-stationary form for dense data: the wave keeps 256 merged candidates
-// [p0, p0+256) in registers (four per lane, two packed pairs) and tests them
-// against every home particle h[h_lo..h_hi), whose coordinates arrive as LDS
-// broadcasts.  All candidates in [c_lo, c_hi) are valid partners, except that
+// Candidate-stationary form for dense data: the wave keeps the 128*PAIRS merged
+// candidates [p0, p0 + 128*PAIRS) in registers (PAIRS packed pairs per lane) and
+// tests them against every home particle h[h_lo..h_hi), whose coordinates arrive
+// as LDS broadcasts.  All candidates below c_hi are valid partners, except that
 // with USE_LO a home particle only pairs with candidates at or after its own
 // meta.x & 0xFFFF (the "later slots of the same cell" rule of main.c:215-221).
+template <bool USE_LO, int PAIRS>
+__device__ __forceinline__ uint32_t pc_g_chunk(const pc_group_lds &L, uint32_t p0, uint32_t c_hi,
+                                               uint32_t h_lo, uint32_t h_hi, int lane)
+{
+    uint32_t hits = 0;
+    const uint32_t p = p0 + lane;
+    pc_v2f x[PAIRS], y[PAIRS], z[PAIRS];
+    unsigned long long ok[2 * PAIRS];
+#pragma unroll
+    for (int c = 0; c < PAIRS; c++) {
+        x[c] = pc_v2f{L.x[p + 128 * c], L.x[p + 128 * c + 64]};
+        y[c] = pc_v2f{L.y[p + 128 * c], L.y[p + 128 * c + 64]};
+        z[c] = pc_v2f{L.z[p + 128 * c], L.z[p + 128 * c + 64]};
+        ok[2 * c] = __builtin_amdgcn_ballot_w64(p + 128 * c < c_hi);
+        ok[2 * c + 1] = __builtin_amdgcn_ballot_w64(p + 128 * c + 64 < c_hi);
+    }
+    for (uint32_t hp = h_lo; hp < h_hi; hp++) {
+        const float hx = L.hx[hp], hy = L.hy[hp], hz = L.hz[hp];
+        const pc_v2f ax = {hx, hx}, ay = {hy, hy}, az = {hz, hz};
+        uint32_t lo = 0;
+        if (USE_LO) lo = L.meta[hp].x & 0xFFFFu;
+#pragma unroll
+        for (int c = 0; c < PAIRS; c++) {
+            const pc_v2f dx = ax - x[c], dy = ay - y[c], dz = az - z[c];
+            const pc_v2f sq = (dx * dx + dy * dy) + dz * dz;
+            unsigned long long b0 = __builtin_amdgcn_ballot_w64(sq.x <= 0.0025f) & ok[2 * c];
+            unsigned long long b1 = __builtin_amdgcn_ballot_w64(sq.y <= 0.0025f) & ok[2 * c + 1];
+            if (USE_LO) {
+                b0 &= __builtin_amdgcn_ballot_w64(p + 128 * c >= lo);
+                b1 &= __builtin_amdgcn_ballot_w64(p + 128 * c + 64 >= lo);
+            }
+            hits += __popcll(b0) + __popcll(b1);
+        }
+    }
+    return hits;
+}
+
+// candidates [c_lo, c_hi) in chunks of 256, the last one 128 wide if that is enough
 template <bool USE_LO>
 __device__ __forceinline__ uint32_t pc_g_block(const pc_group_lds &L, uint32_t c_lo, uint32_t c_hi,
                                                uint32_t h_lo, uint32_t h_hi, int lane)
@@ -231,38 +269,13 @@ __device__ __forceinline__ uint32_t pc_g_block(const pc_group_lds &L, uint32_t c
     uint32_t hits = 0;
     c_lo = __builtin_amdgcn_readfirstlane(c_lo); c_hi = __builtin_amdgcn_readfirstlane(c_hi);
     h_lo = __builtin_amdgcn_readfirstlane(h_lo); h_hi = __builtin_amdgcn_readfirstlane(h_hi);
-    for (uint32_t p0 = c_lo; p0 < c_hi; p0 += 256) {
-        const uint32_t p = p0 + lane;
-        const pc_v2f x01 = {L.x[p], L.x[p + 64]}, x23 = {L.x[p + 128], L.x[p + 192]};
-        const pc_v2f y01 = {L.y[p], L.y[p + 64]}, y23 = {L.y[p + 128], L.y[p + 192]};
-        const pc_v2f z01 = {L.z[p], L.z[p + 64]}, z23 = {L.z[p + 128], L.z[p + 192]};
-        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(p < c_hi), m1 = __builtin_amdgcn_ballot_w64(p + 64 < c_hi),
-                                 m2 = __builtin_amdgcn_ballot_w64(p + 128 < c_hi), m3 = __builtin_amdgcn_ballot_w64(p + 192 < c_hi);
-        for (uint32_t hp = h_lo; hp < h_hi; hp++) {
-            const float hx = L.hx[hp], hy = L.hy[hp], hz = L.hz[hp];
-            const pc_v2f ax = {hx, hx}, ay = {hy, hy}, az = {hz, hz};
-            const pc_v2f dx01 = ax - x01, dy01 = ay - y01, dz01 = az - z01;
-            const pc_v2f dx23 = ax - x23, dy23 = ay - y23, dz23 = az - z23;
-            const pc_v2f s01 = (dx01 * dx01 + dy01 * dy01) + dz01 * dz01;
-            const pc_v2f s23 = (dx23 * dx23 + dy23 * dy23) + dz23 * dz23;
-            unsigned long long b0 = __builtin_amdgcn_ballot_w64(s01.x <= 0.0025f) & m0;
-            unsigned long long b1 = __builtin_amdgcn_ballot_w64(s01.y <= 0.0025f) & m1;
-            unsigned long long b2 = __builtin_amdgcn_ballot_w64(s23.x <= 0.0025f) & m2;
-            unsigned long long b3 = __builtin_amdgcn_ballot_w64(s23.y <= 0.0025f) & m3;
-            if (USE_LO) {
-                const uint32_t lo = L.meta[hp].x & 0xFFFFu;
-                b0 &= __builtin_amdgcn_ballot_w64(p >= lo);
-                b1 &= __builtin_amdgcn_ballot_w64(p + 64 >= lo);
-                b2 &= __builtin_amdgcn_ballot_w64(p + 128 >= lo);
-                b3 &= __builtin_amdgcn_ballot_w64(p + 192 >= lo);
-            }
-            hits += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
-        }
-    }
+    uint32_t p0 = c_lo;
+    for (; p0 + 128 < c_hi; p0 += 256) hits += pc_g_chunk<USE_LO, 2>(L, p0, c_hi, h_lo, h_hi, lane);
+    if (p0 < c_hi) hits += pc_g_chunk<USE_LO, 1>(L, p0, c_hi, h_lo, h_hi, lane);
     return hits;
 }
 
-__global__ void __launch_bounds__(PC_G_WAVES * 64, 4)   // 4 waves per SIMD (a fifth would fit the LDS but spills registers)
+__global__ void __launch_bounds__(PC_G_WAVES * 64, 4)   // registers and LDS admit 5 waves per SIMD
 pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T, int x_lo, int x_hi,
                    unsigned int *__restrict__ queue, unsigned long long *__restrict__ out)
 {
