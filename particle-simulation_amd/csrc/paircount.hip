@@ -288,11 +288,13 @@ static int bin_layers(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
     return PC_OK;
 }
 
-// Work counters of the persistent pair-test kernel: a small array in the code
-// object (each device holds its own copy), zeroed on the launch stream before
-// every launch.  Two pair-test launches that overlap on one device would share
-// it; the library's own entry points never overlap launches on a device.
-static __device__ __align__(256) unsigned int pc_count_queue_words[8 * PC_G_QUEUE_STRIDE];
+// Work area of the persistent pair-test kernel (layout: pc_count_group.h): work
+// counters, the per-pencil "planned" flags and the segment list, 2.2 MB in the
+// code object (each device holds its own copy).  The counters are zeroed on the
+// launch stream before every launch, flags and segments are rewritten by the
+// planning kernel.  Two pair-test launches that overlap on one device would
+// share it; the library's own entry points never overlap launches on a device.
+static __device__ __align__(256) unsigned int pc_count_queue_words[PC_G_WORK_WORDS];
 static unsigned int *g_queue_ptr[64];
 static pthread_mutex_t g_queue_lock = PTHREAD_MUTEX_INITIALIZER;
 
@@ -343,7 +345,9 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
         unsigned int *queue = nullptr;
         int rc2 = count_queue(&queue);
         if (rc2) return rc2;
-        PC_HIP(hipMemsetAsync(queue, 0, 8 * PC_G_QUEUE_STRIDE * sizeof(unsigned int), (hipStream_t)stream));
+        PC_HIP(hipMemsetAsync(queue, 0, PC_G_FLAGS * sizeof(unsigned int), (hipStream_t)stream));   // all counters
+        const dim3 plan_grid(((x_hi - x_lo) * PC_NLAYERS + 255) / 256);
+        PC_LAUNCH("pc_c3_plan", pc_c3_plan, plan_grid, dim3(256), (hipStream_t)stream, d_cell_start, x_lo, x_hi, queue);
         // as many workgroups as are resident at once (registers and LDS decide: asked of the runtime, once)
         static int resident_on[64];               // per device ordinal (count_queue has checked the range)
         int dev = 0;

@@ -34,6 +34,26 @@
 #define PC_G_CAPH 128                   // row-0 points per window; a multiple of 64
 #define PC_G_BAND (PC_NLAYERS / 8)
 #define PC_G_QUEUE_STRIDE 32             // one work counter per XCD group, each on its own 128-byte line
+// Heavy pencils (clustered inputs) are cut into z segments of roughly equal cost
+// by a planning kernel and handed out one segment at a time after the whole
+// pencils.  Layout of the work area (32-bit words):
+//   [0, 256)                      the eight band counters
+//   [PC_G_SEG_COUNT]              segments planned        [PC_G_SEG_DRAW] segments handed out
+//   [PC_G_FLAGS, +PC_G_FLAG_WORDS)   one byte per pencil: 1 = planned as segments
+//   [PC_G_SEGS, +2*PC_G_SEG_CAP)     segments: pencil + 1 (0 = empty slot), z_begin | z_end << 16
+#define PC_G_SEG_COUNT 256
+#define PC_G_SEG_DRAW 288
+#define PC_G_FLAGS 320
+#define PC_G_FLAG_WORDS ((PC_NBB * PC_NBB + 3) / 4 + 3)
+#define PC_G_SEGS (PC_G_FLAGS + PC_G_FLAG_WORDS)
+#define PC_G_SEG_CAP 262144
+#define PC_G_WORK_WORDS (PC_G_SEGS + 2 * PC_G_SEG_CAP)
+#ifndef PC_G_PLAN_MIN_POINTS
+#define PC_G_PLAN_MIN_POINTS 2048        // pencils with fewer points are never cut
+#endif
+#ifndef PC_G_PLAN_TARGET
+#define PC_G_PLAN_TARGET 70000u          // cost of one segment, in units of n_c * (n_{c-1} + n_c + n_{c+1}) (about 4.5 tests each)
+#endif
 #define PC_G_WG_PER_BAND ((PC_G_BAND + PC_G_WAVES - 1) / PC_G_WAVES)
 
 typedef float pc_v2f __attribute__((ext_vector_type(2)));
@@ -275,6 +295,63 @@ __device__ __forceinline__ uint32_t pc_g_block(const pc_group_lds &L, uint32_t c
     return hits;
 }
 
+// Planning: one thread per home pencil of the slab.  A pencil with many points is
+// cut where the running cost estimate passes PC_G_PLAN_TARGET; its segments are
+// appended to the list (all of them or, if the list is full, none) and its flag
+// tells the pair test to leave the pencil to the segment phase.
+// The walk below either counts the segments of a pencil or writes them from
+// position `slot` on; they always cover the cells [0, 400) exactly.
+template <bool WRITE>
+__device__ __forceinline__ uint32_t pc_plan_walk(const uint32_t *__restrict__ row, uint32_t pencil,
+                                                 unsigned int *__restrict__ work, uint32_t slot, unsigned long long target)
+{
+    uint32_t segs = 0, prev = 0, cur = row[1] - row[0];
+    unsigned long long acc = 0;
+    int z_begin = 0;
+    for (int c = 0; c < PC_NLAYERS; c++) {
+        const uint32_t next = row[c + 2] - row[c + 1];
+        acc += (unsigned long long)cur * (prev + cur + next);
+        prev = cur;
+        cur = next;
+        if (acc >= target || c == PC_NLAYERS - 1) {
+            if (WRITE) {
+                work[PC_G_SEGS + 2 * (slot + segs)] = pencil + 1;
+                work[PC_G_SEGS + 2 * (slot + segs) + 1] = (uint32_t)z_begin | ((uint32_t)(c + 1) << 16);
+            }
+            segs++;
+            z_begin = c + 1;
+            acc = 0;
+        }
+    }
+    return segs;
+}
+
+__global__ void __launch_bounds__(256)
+pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__restrict__ work)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= (x_hi - x_lo) * PC_NLAYERS) return;
+    const int layer = x_lo + t / PC_NLAYERS, j = t % PC_NLAYERS;
+    const uint32_t pencil = (uint32_t)layer * PC_NBB + j;
+    const uint32_t *row = T + (uint64_t)pencil * PC_NBB;
+    unsigned char planned = 0;
+    if (row[PC_NLAYERS] - row[0] >= PC_G_PLAN_MIN_POINTS) {
+        const unsigned long long target = PC_G_PLAN_TARGET;
+        const uint32_t segs = pc_plan_walk<false>(row, pencil, work, 0, target);
+        if (segs >= 2) {
+            const uint32_t at = atomicAdd(work + PC_G_SEG_COUNT, segs);
+            if (at + segs <= PC_G_SEG_CAP) {
+                pc_plan_walk<true>(row, pencil, work, at, target);
+                planned = 1;
+            } else {
+                // the list is full: the pencil stays whole, the slots it reserved below the cap stay empty
+                for (uint32_t q = at; q < PC_G_SEG_CAP; q++) work[PC_G_SEGS + 2 * q] = 0;
+            }
+        }
+    }
+    reinterpret_cast<unsigned char *>(work + PC_G_FLAGS)[pencil] = planned;
+}
+
 __global__ void __launch_bounds__(PC_G_WAVES * 64, 4)   // registers and LDS admit 5 waves per SIMD
 pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T, int x_lo, int x_hi,
                    unsigned int *__restrict__ queue, unsigned long long *__restrict__ out)
@@ -293,22 +370,52 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
     // is hidden).  When its own band is used up a wave moves on to the next
     // group's band (clustered inputs load the bands unevenly); it leaves the loop
     // once it has seen all eight counters past the end.
+    //
+    // Pencils the planning kernel has cut into segments are skipped in this first
+    // phase; in the second phase the waves draw those segments, one at a time,
+    // from a single counter.
     int g = blockIdx.x & 7, bands_done = 0;
     const int band_pencils = (x_hi - x_lo) * PC_G_BAND;
+    const unsigned char *planned = reinterpret_cast<const unsigned char *>(queue + PC_G_FLAGS);
+    bool segment_phase = false;
+    int n_segments = 0;
     int m = 0;
     if (lane == 0) m = (int)atomicAdd(queue + g * PC_G_QUEUE_STRIDE, 1u);
     m = __builtin_amdgcn_readfirstlane(m);
     for (;;) {
-        while (m >= band_pencils && ++bands_done < 8) {
-            g = (g + 1) & 7;
-            if (lane == 0) m = (int)atomicAdd(queue + g * PC_G_QUEUE_STRIDE, 1u);
-            m = __builtin_amdgcn_readfirstlane(m);
+        int layer, j, z_begin = 0, z_end = PC_NLAYERS, m_next = 0;
+        uint32_t skip = 0;                                 // first phase: non-zero if the pencil is left to the segment phase
+        if (!segment_phase) {
+            while (m >= band_pencils && ++bands_done < 8) {
+                g = (g + 1) & 7;
+                if (lane == 0) m = (int)atomicAdd(queue + g * PC_G_QUEUE_STRIDE, 1u);
+                m = __builtin_amdgcn_readfirstlane(m);
+            }
+            if (m >= band_pencils) {
+                segment_phase = true;
+                n_segments = (int)min(__builtin_amdgcn_readfirstlane(queue[PC_G_SEG_COUNT]), (uint32_t)PC_G_SEG_CAP);
+                if (lane == 0) m = (int)atomicAdd(queue + PC_G_SEG_DRAW, 1u);
+                m = __builtin_amdgcn_readfirstlane(m);
+                continue;
+            }
+            if (lane == 0) m_next = (int)atomicAdd(queue + g * PC_G_QUEUE_STRIDE, 1u);
+            layer = x_lo + m / PC_G_BAND;
+            j = g * PC_G_BAND + m % PC_G_BAND;
+            skip = planned[layer * PC_NBB + j];             // (requested together with the table entries below)
+        } else {
+            if (m >= n_segments) break;
+            if (lane == 0) m_next = (int)atomicAdd(queue + PC_G_SEG_DRAW, 1u);
+            const uint32_t who = __builtin_amdgcn_readfirstlane(queue[PC_G_SEGS + 2 * m]);
+            const uint32_t span = __builtin_amdgcn_readfirstlane(queue[PC_G_SEGS + 2 * m + 1]);
+            if (who == 0) {                                // slot left empty by a pencil that did not fit the list
+                m = __builtin_amdgcn_readfirstlane(m_next);
+                continue;
+            }
+            layer = (int)((who - 1) / PC_NBB);
+            j = (int)((who - 1) % PC_NBB);
+            z_begin = (int)(span & 0xFFFFu);
+            z_end = (int)(span >> 16);
         }
-        if (m >= band_pencils) break;
-        int m_next = 0;
-        if (lane == 0) m_next = (int)atomicAdd(queue + g * PC_G_QUEUE_STRIDE, 1u);
-        const int layer = x_lo + m / PC_G_BAND;
-        const int j = g * PC_G_BAND + m % PC_G_BAND;
         // table bases of the five rows; invalid rows (outside the occupied grid) are empty
         const int ri[5] = {layer, layer, layer + 1, layer + 1, layer + 1};
         const int rj[5] = {j, j + 1, j - 1, j, j + 1};
@@ -319,9 +426,10 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
             valid[r] = ri[r] < PC_NLAYERS && rj[r] >= 0 && rj[r] < PC_NLAYERS;
             tb[r] = valid[r] ? ((uint32_t)ri[r] * PC_NBB + rj[r]) * PC_NBB : 0u;
         }
-        const uint32_t home_lo = T[tb[0]], home_hi = T[tb[0] + PC_NBB];
-        int z0 = 0;
-        uint32_t done = home_lo;         // first home slot not yet processed
+        // home cells [z_begin, z_end) of the pencil (all of it unless this is a planned segment)
+        const uint32_t home_lo = T[tb[0] + z_begin], home_hi = T[tb[0] + z_end];
+        int z0 = z_begin;
+        uint32_t done = skip ? home_hi : home_lo;          // first home slot not yet processed
         // table entries of the current window: lane t holds, per row, the start of
         // cell zl+t and of the cell after it.  The next window's entries are
         // requested as soon as its position is known, so they arrive while the
@@ -329,11 +437,11 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
         uint32_t a0[5], a1[5];
 #pragma unroll
         for (int r = 0; r < 5; r++) {
-            const uint32_t *e = T + (tb[r] + (uint32_t)min(lane, PC_NBB - 1));
+            const uint32_t *e = T + (tb[r] + (uint32_t)min((z_begin > 0 ? z_begin - 1 : 0) + lane, PC_NBB - 1));
             a0[r] = e[0];
             a1[r] = e[1];
         }
-        while (done != home_hi && z0 < PC_NLAYERS) {
+        while (done != home_hi && z0 < z_end) {
             const int zl = z0 > 0 ? z0 - 1 : 0;
             const int th0 = z0 - zl;                       // window index of the first home cell (0 or 1)
             // ---- lane t owns window cell zl + t: per-row starts and counts
@@ -350,7 +458,8 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
             const uint32_t nm = (nm_pts + 1) & ~1u;
             const uint32_t cum_m = pc_wave_incl_scan(nm), cum_h = pc_wave_incl_scan(n[0]);
             // longest window that fits both buffers (feasible lanes form a prefix)
-            const int nfit = __popcll(__builtin_amdgcn_ballot_w64(cum_m <= PC_G_CAPM && cum_h <= PC_G_CAPH));
+            // and ends at cell z_end at the latest (the last window cell only supplies candidates)
+            const int nfit = __popcll(__builtin_amdgcn_ballot_w64(cum_m <= PC_G_CAPM && cum_h <= PC_G_CAPH && zl + lane <= z_end));
             const int t_last = nfit - 1;                   // last window cell; home cells are th0 .. t_last-1
             const bool fits = t_last >= th0 + 1;
             const int z_next = fits ? zl + t_last : z0 + 1;
