@@ -404,20 +404,36 @@ pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
     } else {
         // more points than the registers hold: histogram sweep, then a second sweep
         // that claims slots through LDS cursors
-        for (uint32_t i = lane; i < n; i += 64) {
-            const int k = pc_cell_index(g[i].z);
-            if ((unsigned)k < 400u) atomicAdd(&hist[k], 1u);
-            else bad = true;
+        // (eight loads in flight per lane and sweep: one memory round trip per 512 points)
+        for (uint32_t i0 = 0; i0 < n; i0 += 512) {
+            float zs[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) zs[q] = g[min(i0 + 64u * q + lane, n - 1)].z;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (i0 + 64u * q + lane < n) {
+                    const int k = pc_cell_index(zs[q]);
+                    if ((unsigned)k < 400u) atomicAdd(&hist[k], 1u);
+                    else bad = true;
+                }
+            }
         }
         pc_wave_lds_sync();
         pc_l7_scan_bins(hist, lane);
         pc_wave_lds_sync();
         for (int k = lane; k < PC_NBB; k += 64) slice[k] = base + hist[k];
         pc_wave_lds_sync();
-        for (uint32_t i = lane; i < n; i += 64) {
-            const pc_pt3 v = g[i];
-            const int k = pc_cell_index(v.z);
-            if ((unsigned)k < 400u) o[atomicAdd(&hist[k], 1u)] = v;
+        for (uint32_t i0 = 0; i0 < n; i0 += 512) {
+            pc_pt3 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = g[min(i0 + 64u * q + lane, n - 1)];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (i0 + 64u * q + lane < n) {
+                    const int k = pc_cell_index(v[q].z);
+                    if ((unsigned)k < 400u) o[atomicAdd(&hist[k], 1u)] = v[q];
+                }
+            }
         }
     }
     if (bad) atomicOr(status, 1);
