@@ -206,8 +206,15 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
         PC_LAUNCH("pc_l6_partition_y", pc_l36_partition<1>, dim3(tiles + PC_NBB), dim3(PC_L_PTPB), s, d_sorted, n,
                   w.tmp, w.layer_start, w.layer_tile, w.tile_layer, w.pencil_cursor, w.ycell);
     const uint32_t first_pencil = (uint32_t)layer_lo * PC_NBB, end_pencil = (uint32_t)(layer_hi + 1) * PC_NBB;
-    PC_LAUNCH("pc_l7_sort_pencils", pc_l7_sort_pencils, dim3((end_pencil - first_pencil + PC_L7_WAVES - 1) / PC_L7_WAVES),
-              dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted, w.pencil_start, table, first_pencil, end_pencil, d_status);
+    // sparse inputs (at most half the small capacity per occupied pencil on average) take the low-LDS form
+    const dim3 l7_grid((end_pencil - first_pencil + PC_L7_WAVES - 1) / PC_L7_WAVES);
+    const uint64_t occupied_pencils = (uint64_t)(layer_hi < PC_NLAYERS ? layer_hi - layer_lo + 1 : PC_NLAYERS - layer_lo) * PC_NLAYERS;
+    if (n * 2 <= occupied_pencils * PC_L7_CAP_SPARSE)
+        PC_LAUNCH("pc_l7_sort_pencils", pc_l7_sort_pencils<PC_L7_CAP_SPARSE>, l7_grid, dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted,
+                  w.pencil_start, table, first_pencil, end_pencil, d_status);
+    else
+        PC_LAUNCH("pc_l7_sort_pencils", pc_l7_sort_pencils<PC_L7_CAP>, l7_grid, dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted,
+                  w.pencil_start, table, first_pencil, end_pencil, d_status);
     PC_HIP(hipGetLastError());
     return PC_OK;
 }

@@ -308,8 +308,8 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
 // window of a few KB that this one wave writes completely, so the 12-byte stores,
 // scattered inside that window, merge into full lines in the XCD's L2.
 #define PC_L7_WAVES 2
-#define PC_L7_CAP 768                                  // points a wave keeps in registers and stages in LDS
-#define PC_L7_PPL (PC_L7_CAP / 64)
+#define PC_L7_CAP 768                                  // points a wave keeps in registers and stages in LDS ...
+#define PC_L7_CAP_SPARSE 192                           // ... and for sparse inputs (less LDS per wave, more waves per CU)
 
 
 // exclusive scan of the wave's 404 bin counts in place (lane l owns bins 7l..7l+6)
@@ -331,13 +331,15 @@ __device__ __forceinline__ void pc_l7_scan_bins(uint32_t *hist, int lane)
     }
 }
 
+template <int CAP>
 __global__ void __launch_bounds__(PC_L7_WAVES * 64)
 pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
                    const uint32_t *__restrict__ pencil_start, uint32_t *__restrict__ table,
                    uint32_t first_pencil, uint32_t end_pencil, int32_t *__restrict__ status)
 {
     __shared__ uint32_t hist_all[PC_L7_WAVES][PC_L_BINS];
-    __shared__ __attribute__((aligned(16))) float stage_all[PC_L7_WAVES][PC_L7_CAP * 3 + 4];
+    constexpr int PPL = CAP / 64;                      // points per lane
+    __shared__ __attribute__((aligned(16))) float stage_all[PC_L7_WAVES][CAP * 3 + 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t *hist = hist_all[wave];
     // pencils [first_pencil, end_pencil): all of them, or the layers one slab's pair test reads
@@ -356,15 +358,15 @@ pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
     pc_pt3 *o = reinterpret_cast<pc_pt3 *>(dst) + base;
     bool bad = false;
 
-    if (n <= PC_L7_CAP) {
+    if (n <= CAP) {
         const int rounds = (int)((n + 63) >> 6);       // wave-uniform
-        pc_pt3 pt[PC_L7_PPL];
-        uint32_t tag[PC_L7_PPL];
+        pc_pt3 pt[PPL];
+        uint32_t tag[PPL];
 #pragma unroll
-        for (int j = 0; j < PC_L7_PPL; j++)            // all loads first: one memory round trip
+        for (int j = 0; j < PPL; j++)            // all loads first: one memory round trip
             if (j < rounds) pt[j] = g[min(lane + 64u * j, n - 1)];
 #pragma unroll
-        for (int j = 0; j < PC_L7_PPL; j++) {
+        for (int j = 0; j < PPL; j++) {
             tag[j] = 0xFFFFFFFFu;
             if (j < rounds && lane + 64u * j < n) {
                 const int k = pc_cell_index(pt[j].z);
@@ -384,7 +386,7 @@ pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
         const uint32_t shift = (uint32_t)((reinterpret_cast<uintptr_t>(od) >> 2) & 3u);
         uint32_t kept = 0;
 #pragma unroll
-        for (int j = 0; j < PC_L7_PPL; j++) {
+        for (int j = 0; j < PPL; j++) {
             if (j < rounds && tag[j] != 0xFFFFFFFFu) {
                 const uint32_t pos = shift + 3u * (hist[tag[j] & 1023u] + (tag[j] >> 10));
                 stage[pos] = pt[j].x; stage[pos + 1] = pt[j].y; stage[pos + 2] = pt[j].z;
