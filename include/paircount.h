@@ -116,7 +116,12 @@ int pc_bin_device(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
    (main.c:85-91,161-234): ADDS to *d_npairs (uint64, caller zeroes) the number
    of pairs (a,b), a in a home cell with x index in [x_lo,x_hi), b later in the
    same cell or anywhere in its 13 forward neighbour cells (main.c:195-209),
-   with (dx*dx+dy*dy)+dz*dz <= 0.0025f in unfused binary32. */
+   with (dx*dx+dy*dy)+dz*dz <= 0.0025f in unfused binary32.
+   The kernels keep their work counters and the list of heavy-pencil segments
+   in one per-device area inside the library: calls of this function (and of
+   pc_count_pairs_device / pc_finish, which use it) that could overlap on one
+   device -- different streams, different host threads -- must be serialised by
+   the caller. */
 int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t *d_cell_start,
                            uint64_t n, int x_lo, int x_hi, uint64_t *d_npairs,
                            void *stream);
