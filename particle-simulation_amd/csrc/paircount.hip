@@ -571,6 +571,14 @@ struct finish_bufs {
     }
 };
 
+static pthread_mutex_t g_finish_lock[64] = {
+#define PC_M4 PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER
+#define PC_M16 PC_M4, PC_M4, PC_M4, PC_M4
+    PC_M16, PC_M16, PC_M16, PC_M16
+#undef PC_M16
+#undef PC_M4
+};
+
 extern "C" int pc_finish(pc_context *c, int64_t *npairs)
 {
     if (!c || !npairs) return pc_fail(PC_ERR_ARG, "pc_finish: null pointer");
@@ -593,6 +601,12 @@ extern "C" int pc_finish(pc_context *c, int64_t *npairs)
         return pc_fail(PC_ERR_NOMEM, "pc_finish: device allocation failed for %llu points", (unsigned long long)n);
     for (auto &e : b.ev) PC_HIP(hipEventCreate(&e));
     hipStream_t s = nullptr;
+    // one finish at a time per device: the pair test's work area is per device (see count_queue)
+    struct device_turn {
+        pthread_mutex_t *m;
+        explicit device_turn(pthread_mutex_t *mm) : m(mm) { pthread_mutex_lock(m); }
+        ~device_turn() { pthread_mutex_unlock(m); }
+    } turn(&g_finish_lock[c->device & 63]);
     PC_HIP(hipMemsetAsync(b.res, 0, 16, s));
     PC_HIP(hipMemsetAsync(b.status, 0, 4, s));
     PC_HIP(hipEventRecord(b.ev[0], s));

@@ -284,3 +284,26 @@ def test_density_regimes(psa, stages, torch_mod, oracle, shape):
         got, tests, _ = gpu_count(psa, stages, torch_mod, xyz, bin_v=bv, count_v=cv)
         assert got == want, (shape, bv, cv)
         assert tests == want_tests
+
+
+def test_two_contexts_finish_concurrently(psa, torch_mod, oracle):
+    """Two streaming contexts on one device, finished from two threads at once:
+    the library serialises them (the pair test has one work area per device)."""
+    import threading
+    rng = np.random.default_rng(21)
+    sets = [rng.uniform(-2.0, 2.0, (250_000, 3)).astype(np.float32),
+            _cell_box(rng, 30_000, (50, 60, 0), (51, 61, 400)).astype(np.float32)]   # the second one has planned segments
+    want = [oracle.count_pairs(x)[0] for x in sets]
+    for _ in range(3):
+        pcs = [psa.PairCounter(device=0, expected_points=len(x)) for x in sets]
+        for pc, x in zip(pcs, sets):
+            pc.append(x)
+        got = [None, None]
+
+        def finish(i):
+            got[i] = pcs[i].finish()
+        th = [threading.Thread(target=finish, args=(i,)) for i in range(2)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert got == want
+        [pc.close() for pc in pcs]
