@@ -54,7 +54,7 @@ def kernel_bytes(name, n, layers):
         "pc_l3_partition_x": 24 * n + 2 * n,                # points in and out, y cells out
         "pc_l4_hist_y": 2 * n,                              # y cells in
         "pc_l6_partition_y": 24 * n,
-        "pc_l7_sort_pencils": 24 * n + 4 * all_cells,
+        "pc_l7_sort_pencils": 24 * n + 4 * all_cells,       # (with pc_l7b_sort_big_pencils, which takes the pencils too big for a wave)
     }
     return table.get(name)
 

@@ -154,7 +154,8 @@ static inline int grid_for(uint64_t n, int tpb, int cap);
 static inline size_t lds_ws_counters(uint64_t n)
 {
     return (size_t)PC_L_NREP * PC_L_BINS + (size_t)PC_L_NREP * PC_L_PSTRIDE + PC_L_BINS + (size_t)PC_L_NREP * PC_L_BINS + PC_L_BINS +
-           ((n + PC_L_TILE - 1) / PC_L_TILE + PC_L_BINS) + (PC_L_NPENCILS + 1) + (size_t)PC_L_NREP * PC_L_PSTRIDE;
+           ((n + PC_L_TILE - 1) / PC_L_TILE + PC_L_BINS) + (PC_L_NPENCILS + 1) + (size_t)PC_L_NREP * PC_L_PSTRIDE +
+           8 + PC_L_NPENCILS;
 }
 
 extern "C" size_t pc_workspace_bytes(uint64_t n)
@@ -173,12 +174,14 @@ static pc_lds_ws carve_lds_ws(void *ws, uint64_t n)
     uint32_t *u = (uint32_t *)((char *)ws + align_up((size_t)n * 12 + 16, 256));
     w.layer_count = u;            u += PC_L_NREP * PC_L_BINS;
     w.pencil_count = u;           u += PC_L_NREP * PC_L_PSTRIDE;
+    w.big_count = u;              u += 8;                       // (zeroed together with the two arrays before it)
     w.layer_start = u;            u += PC_L_BINS;
     w.layer_cursor = u;           u += PC_L_NREP * PC_L_BINS;
     w.layer_tile = u;             u += PC_L_BINS;
     w.tile_layer = u;             u += (n + PC_L_TILE - 1) / PC_L_TILE + PC_L_BINS;
     w.pencil_start = u;           u += PC_L_NPENCILS + 1;
-    w.pencil_cursor = u;
+    w.pencil_cursor = u;          u += PC_L_NREP * PC_L_PSTRIDE;
+    w.big_list = u;
     w.ycell = (uint16_t *)((char *)ws + align_up((size_t)n * 12 + 16, 256) + align_up(lds_ws_counters(n) * 4, 256));
     return w;
 }
@@ -188,7 +191,7 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
                    int32_t *d_status, hipStream_t s, int layer_lo, int layer_hi)
 {
     pc_lds_ws w = carve_lds_ws(ws, n);
-    PC_HIP(hipMemsetAsync(w.layer_count, 0, (PC_L_NREP * PC_L_BINS + PC_L_NREP * PC_L_PSTRIDE) * sizeof(uint32_t), s));
+    PC_HIP(hipMemsetAsync(w.layer_count, 0, (PC_L_NREP * PC_L_BINS + PC_L_NREP * PC_L_PSTRIDE + 8) * sizeof(uint32_t), s));
     const int tiles = (int)((n + PC_L_TILE - 1) / PC_L_TILE);
     if (n) PC_LAUNCH("pc_l1_hist_x", pc_l1_hist_x, dim3(grid_for(n, PC_L_TILE, 2048)), dim3(PC_L_TPB), s,
                      d_xyz, n, w.layer_count, d_status);
@@ -200,21 +203,25 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
         PC_LAUNCH("pc_l4_hist_y", pc_l4_hist_y, dim3(tiles + PC_NBB), dim3(PC_L_TPB), s, w.ycell, w.layer_start,
                   w.layer_tile, w.tile_layer, w.pencil_count, d_status);
     }
+    // sparse inputs (at most half the small capacity per occupied pencil on average) take the low-LDS form of L7
+    const uint64_t occupied_pencils = (uint64_t)(layer_hi < PC_NLAYERS ? layer_hi - layer_lo + 1 : PC_NLAYERS - layer_lo) * PC_NLAYERS;
+    const bool sparse = n * 2 <= occupied_pencils * PC_L7_CAP_SPARSE;
     PC_LAUNCH("pc_l5_scan_y", pc_l5_scan_y, dim3(PC_NBB), dim3(512), s, w.pencil_count, w.layer_start,
-              w.pencil_start, w.pencil_cursor);
+              w.pencil_start, w.pencil_cursor, (uint32_t)(sparse ? PC_L7_CAP_SPARSE : PC_L7_CAP), w.big_count, w.big_list);
     if (n)
         PC_LAUNCH("pc_l6_partition_y", pc_l36_partition<1>, dim3(tiles + PC_NBB), dim3(PC_L_PTPB), s, d_sorted, n,
                   w.tmp, w.layer_start, w.layer_tile, w.tile_layer, w.pencil_cursor, w.ycell);
     const uint32_t first_pencil = (uint32_t)layer_lo * PC_NBB, end_pencil = (uint32_t)(layer_hi + 1) * PC_NBB;
-    // sparse inputs (at most half the small capacity per occupied pencil on average) take the low-LDS form
     const dim3 l7_grid((end_pencil - first_pencil + PC_L7_WAVES - 1) / PC_L7_WAVES);
-    const uint64_t occupied_pencils = (uint64_t)(layer_hi < PC_NLAYERS ? layer_hi - layer_lo + 1 : PC_NLAYERS - layer_lo) * PC_NLAYERS;
-    if (n * 2 <= occupied_pencils * PC_L7_CAP_SPARSE)
+    if (sparse)
         PC_LAUNCH("pc_l7_sort_pencils", pc_l7_sort_pencils<PC_L7_CAP_SPARSE>, l7_grid, dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted,
                   w.pencil_start, table, first_pencil, end_pencil, d_status);
     else
         PC_LAUNCH("pc_l7_sort_pencils", pc_l7_sort_pencils<PC_L7_CAP>, l7_grid, dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted,
                   w.pencil_start, table, first_pencil, end_pencil, d_status);
+    // pencils too big for a wave (listed by L5): one workgroup each, a fixed grid walks the list
+    PC_LAUNCH("pc_l7b_sort_big_pencils", pc_l7b_sort_big_pencils, dim3(1024), dim3(PC_L7B_TPB), s, w.tmp, d_sorted,
+              w.pencil_start, table, w.big_count, w.big_list, first_pencil, end_pencil, d_status);
     PC_HIP(hipGetLastError());
     return PC_OK;
 }

@@ -46,6 +46,8 @@ struct pc_lds_ws {
     uint32_t *pencil_start;   // [162409+1]
     uint32_t *pencil_cursor;  // [NREP][PSTRIDE]
     uint16_t *ycell;          // [N] y cell of every point of the level-X output (0xFFFF: outside the grid)
+    uint32_t *big_count;      // [8] (first word used) number of entries of big_list; zeroed with the counters
+    uint32_t *big_list;       // [162409] pencils with more points than one wave of L7 takes
 };
 
 // ---- L1: histogram of x layers ---------------------------------------------
@@ -165,7 +167,8 @@ pc_l4_hist_y(const uint16_t *__restrict__ ycell, const uint32_t *__restrict__ la
 // rows scan independently: pencil_start[i*403+j] = layer_start[i] + sum_{j'<j}.
 __global__ void __launch_bounds__(512)
 pc_l5_scan_y(const uint32_t *__restrict__ pencil_count, const uint32_t *__restrict__ layer_start,
-             uint32_t *__restrict__ pencil_start, uint32_t *__restrict__ pencil_cursor)
+             uint32_t *__restrict__ pencil_start, uint32_t *__restrict__ pencil_cursor,
+             uint32_t wave_cap, uint32_t *__restrict__ big_count, uint32_t *__restrict__ big_list)
 {
     __shared__ uint32_t a[512];
     const int j = threadIdx.x, layer = blockIdx.x;
@@ -186,6 +189,7 @@ pc_l5_scan_y(const uint32_t *__restrict__ pencil_count, const uint32_t *__restri
     const uint32_t ex = layer_start[layer] + a[j] - c;
     if (j < PC_NBB) {
         pencil_start[layer * PC_NBB + j] = ex;
+        if (c > wave_cap) big_list[atomicAdd(big_count, 1u)] = (uint32_t)(layer * PC_NBB + j);   // sorted by L7B
         uint32_t run = ex;
 #pragma unroll
         for (int g = 0; g < PC_L_NREP; g++) {          // replica sub-regions of the pencil, as in level X
@@ -348,6 +352,7 @@ pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
     const uint32_t base = pencil_start[pencil], n = pencil_start[pencil + 1] - base;
     uint32_t *slice = table + (uint64_t)pencil * PC_NBB;
     if (pencil == PC_L_NPENCILS - 1 && lane < 2) table[(uint64_t)PC_L_NPENCILS * PC_NBB + lane] = base + n;
+    if (n > CAP) return;                               // on the big-pencil list: a whole workgroup of L7B sorts it
     if (n == 0) {
         for (int k = lane; k < PC_NBB; k += 64) slice[k] = base;
         return;
@@ -358,7 +363,7 @@ pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
     pc_pt3 *o = reinterpret_cast<pc_pt3 *>(dst) + base;
     bool bad = false;
 
-    if (n <= CAP) {
+    {
         const int rounds = (int)((n + 63) >> 6);       // wave-uniform
         pc_pt3 pt[PPL];
         uint32_t tag[PPL];
@@ -403,38 +408,84 @@ pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
             *reinterpret_cast<float4 *>(od + head + 4u * q) = *reinterpret_cast<const float4 *>(stage + shift + head + 4u * q);
         const uint32_t t0 = head + 4u * nbody;
         if ((uint32_t)lane < nd - t0) od[t0 + lane] = stage[shift + t0 + lane];
-    } else {
-        // more points than the registers hold: histogram sweep, then a second sweep
-        // that claims slots through LDS cursors
-        // (eight loads in flight per lane and sweep: one memory round trip per 512 points)
-        for (uint32_t i0 = 0; i0 < n; i0 += 512) {
-            float zs[8];
+    }
+    if (bad) atomicOr(status, 1);
+}
+
+// ---- L7B: one workgroup sorts one big pencil ------------------------------------
+// Pencils with more points than a wave of L7 keeps (clustered inputs, or more than
+// about 15 points per cell everywhere) are listed by L5.  Up to PC_L7B_CAP points
+// go through registers and an LDS copy in cell order like L7's; beyond that the
+// pencil is read twice (histogram, then scatter through LDS cursors).
+#define PC_L7B_TPB 512
+#define PC_L7B_CAP 8192
+#define PC_L7B_PPT (PC_L7B_CAP / PC_L7B_TPB)
+
+__global__ void __launch_bounds__(PC_L7B_TPB)
+pc_l7b_sort_big_pencils(const float *__restrict__ src, float *__restrict__ dst,
+                        const uint32_t *__restrict__ pencil_start, uint32_t *__restrict__ table,
+                        const uint32_t *__restrict__ big_count, const uint32_t *__restrict__ big_list,
+                        uint32_t first_pencil, uint32_t end_pencil, int32_t *__restrict__ status)
+{
+    __shared__ uint32_t hist[PC_L_BINS];
+    __shared__ float stage[PC_L7B_CAP * 3];
+    const int tid = threadIdx.x;
+    const uint32_t nbig = *big_count;
+    bool bad = false;
+    for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
+        const uint32_t pencil = big_list[b];
+        if (pencil < first_pencil || pencil >= end_pencil) continue;          // workgroup-uniform
+        const uint32_t base = pencil_start[pencil], n = pencil_start[pencil + 1] - base;
+        uint32_t *slice = table + (uint64_t)pencil * PC_NBB;
+        const pc_pt3 *g = reinterpret_cast<const pc_pt3 *>(src) + base;
+        __syncthreads();                                                     // previous pencil's LDS reads are done
+        for (int k = tid; k < PC_L_BINS; k += PC_L7B_TPB) hist[k] = 0;
+        __syncthreads();
+        if (n <= PC_L7B_CAP) {
+            pc_pt3 pt[PC_L7B_PPT];
+            uint32_t tag[PC_L7B_PPT];
 #pragma unroll
-            for (int q = 0; q < 8; q++) zs[q] = g[min(i0 + 64u * q + lane, n - 1)].z;
+            for (int q = 0; q < PC_L7B_PPT; q++) pt[q] = g[min((uint32_t)(tid + q * PC_L7B_TPB), n - 1)];
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                if (i0 + 64u * q + lane < n) {
-                    const int k = pc_cell_index(zs[q]);
-                    if ((unsigned)k < 400u) atomicAdd(&hist[k], 1u);
+            for (int q = 0; q < PC_L7B_PPT; q++) {
+                tag[q] = 0xFFFFFFFFu;
+                if ((uint32_t)(tid + q * PC_L7B_TPB) < n) {
+                    const int k = pc_cell_index(pt[q].z);
+                    if ((unsigned)k < 400u) tag[q] = (uint32_t)k | (atomicAdd(&hist[k], 1u) << 10);
                     else bad = true;
                 }
             }
-        }
-        pc_wave_lds_sync();
-        pc_l7_scan_bins(hist, lane);
-        pc_wave_lds_sync();
-        for (int k = lane; k < PC_NBB; k += 64) slice[k] = base + hist[k];
-        pc_wave_lds_sync();
-        for (uint32_t i0 = 0; i0 < n; i0 += 512) {
-            pc_pt3 v[8];
+            __syncthreads();
+            if (tid < 64) pc_l7_scan_bins(hist, tid);                        // exclusive starts, in place
+            __syncthreads();
+            for (int k = tid; k < PC_NBB; k += PC_L7B_TPB) slice[k] = base + hist[k];
 #pragma unroll
-            for (int q = 0; q < 8; q++) v[q] = g[min(i0 + 64u * q + lane, n - 1)];
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                if (i0 + 64u * q + lane < n) {
-                    const int k = pc_cell_index(v[q].z);
-                    if ((unsigned)k < 400u) o[atomicAdd(&hist[k], 1u)] = v[q];
+            for (int q = 0; q < PC_L7B_PPT; q++) {
+                if (tag[q] != 0xFFFFFFFFu) {
+                    const uint32_t pos = 3u * (hist[tag[q] & 1023u] + (tag[q] >> 10));
+                    stage[pos] = pt[q].x; stage[pos + 1] = pt[q].y; stage[pos + 2] = pt[q].z;
                 }
+            }
+            __syncthreads();
+            const uint32_t nd = 3u * hist[PC_L_BINS - 1];                     // bins 400..403 are empty: start of bin 403 = points kept
+            float *od = dst + 3 * (uint64_t)base;
+            for (uint32_t d = tid; d < nd; d += PC_L7B_TPB) od[d] = stage[d];
+        } else {
+            for (uint32_t i = tid; i < n; i += PC_L7B_TPB) {
+                const int k = pc_cell_index(g[i].z);
+                if ((unsigned)k < 400u) atomicAdd(&hist[k], 1u);
+                else bad = true;
+            }
+            __syncthreads();
+            if (tid < 64) pc_l7_scan_bins(hist, tid);
+            __syncthreads();
+            for (int k = tid; k < PC_NBB; k += PC_L7B_TPB) slice[k] = base + hist[k];
+            __syncthreads();
+            pc_pt3 *o = reinterpret_cast<pc_pt3 *>(dst) + base;
+            for (uint32_t i = tid; i < n; i += PC_L7B_TPB) {
+                const pc_pt3 v = g[i];
+                const int k = pc_cell_index(v.z);
+                if ((unsigned)k < 400u) o[atomicAdd(&hist[k], 1u)] = v;
             }
         }
     }
