@@ -547,10 +547,15 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                         // same pencil (the steps above count these themselves): lane per home particle
                         for (uint32_t hp = lane; hp < nh; hp += 64) {
                             const float mx = L.hx[hp], my = L.hy[hp], mz = L.hz[hp];
+                            const pc_v2f ax = {mx, mx}, ay = {my, my}, az = {mz, mz};
                             const uint32_t end = L.meta[hp].y;
                             uint32_t cnt = 0;
-                            for (uint32_t k2 = hp + 1; k2 < end; k2++)
-                                cnt += pc_hit(mx, my, mz, L.hx[k2], L.hy[k2], L.hz[k2]);
+                            for (uint32_t k2 = hp + 1; k2 < end; k2 += 2) {       // two candidates per turn
+                                const pc_v2f x = {L.hx[k2], L.hx[k2 + 1]}, y = {L.hy[k2], L.hy[k2 + 1]}, z = {L.hz[k2], L.hz[k2 + 1]};
+                                const pc_v2f dx = ax - x, dy = ay - y, dz = az - z;
+                                const pc_v2f sq = (dx * dx + dy * dy) + dz * dz;
+                                cnt += (sq.x <= 0.0025f) + ((sq.y <= 0.0025f) & (k2 + 1 < end));
+                            }
                             acc += cnt;
                         }
                     }

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--bin-variant", type=int, default=None)
     ap.add_argument("--count-variant", type=int, default=None)
+    ap.add_argument("--as-rank", type=int, nargs=2, metavar=("R", "W"), default=None,
+                    help="the slab rank R of W would hold (equal cuts; weak-scaling workloads use W times the points)")
     args = ap.parse_args()
     import torch
     from __graft_entry__ import load_package
@@ -33,15 +35,24 @@ def main():
         psa.set_variant("bin", args.bin_variant)
     if args.count_variant is not None:
         psa.set_variant("count", args.count_variant)
-    xyz = torch.from_numpy(ht.generate(kind, 7, points, sigma)).to("cuda:0")
-    st = psa.DeviceStages(points, "cuda:0")
+    x_lo, x_hi = 0, 400
+    if args.as_rank:
+        r, w = args.as_rank
+        if bench.WORKLOADS[args.workload][3] == "weak":
+            points *= w
+        x_lo, x_hi = 400 * r // w, 400 * (r + 1) // w
+        host = ht.generate(kind, 7, points, sigma, x_lo=x_lo, x_hi=min(x_hi, 399))
+    else:
+        host = ht.generate(kind, 7, points, sigma)
+    xyz = torch.from_numpy(host).to("cuda:0")
+    st = psa.DeviceStages(xyz.shape[0], "cuda:0")
     n = st.bin(xyz)
     torch.cuda.synchronize()
     for _ in range(args.reps):
         if args.stage in ("bin", "all"):
             st.bin(xyz)
         if args.stage in ("count", "all"):
-            st.count_sorted(n)
+            st.count_sorted(n, x_lo, x_hi)
     torch.cuda.synchronize()
     print("pairs", st.pairs())
 
