@@ -29,7 +29,8 @@ def main():
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; read bytes = 2*FETCH_SIZE*1024 "
                      "(gfx950 half-count correction), write bytes = WRITE_SIZE*1024; per-launch averages",
            "kernels": {}}
-    names = {"pc_l36_partition<0>": "pc_l3_partition_x", "pc_l36_partition<1>": "pc_l6_partition_y"}
+    names = {"pc_l36_partition<0>": "pc_l3_partition_x", "pc_l36_partition<1>": "pc_l6_partition_y",
+             "pc_l7_sort_pencils<768>": "pc_l7_sort_pencils", "pc_l7_sort_pencils<192>": "pc_l7_sort_pencils"}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("pc_"):
             continue
