@@ -150,6 +150,20 @@ static const uint64_t PC_MAX_POINTS = 0xFFFFFFF0ull;   // slots are uint32
 static inline uint32_t scan_tiles(uint64_t m) { return (uint32_t)((m + PC_SCAN_TILE - 1) / PC_SCAN_TILE); }
 static inline int grid_for(uint64_t n, int tpb, int cap);
 
+// Workgroups of `kernel` that are resident on the current device at once (the grid
+// of a kernel whose workgroups loop over a work list); `slot` caches the answer.
+template <typename K>
+static int resident_blocks(K kernel, int tpb, int *slot)
+{
+    if (*slot) return *slot;
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, tpb, 0) != hipSuccess || per_cu < 1)
+        return 1024;
+    return *slot = per_cu * prop.multiProcessorCount;
+}
+
 // uint32 counters of the LDS variant, after its N*12-byte temp array
 static inline size_t lds_ws_counters(uint64_t n)
 {
@@ -219,9 +233,14 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
     else
         PC_LAUNCH("pc_l7_sort_pencils", pc_l7_sort_pencils<PC_L7_CAP>, l7_grid, dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted,
                   w.pencil_start, table, first_pencil, end_pencil, d_status);
-    // pencils too big for a wave (listed by L5): one workgroup each, a fixed grid walks the list
-    PC_LAUNCH("pc_l7b_sort_big_pencils", pc_l7b_sort_big_pencils, dim3(1024), dim3(PC_L7B_TPB), s, w.tmp, d_sorted,
-              w.pencil_start, table, w.big_count, w.big_list, first_pencil, end_pencil, d_status);
+    // pencils too big for a wave (listed by L5): one workgroup each, fixed grids walk the list, one per size class
+    auto small = pc_l7b_sort_big_pencils<PC_L7B_CAP_SMALL, PC_L7B_TPB_SMALL>;
+    auto large = pc_l7b_sort_big_pencils<PC_L7B_CAP_LARGE, PC_L7B_TPB_LARGE>;
+    static int small_grid, large_grid;            // (one device model per process is assumed for these two)
+    PC_LAUNCH("pc_l7b_sort_big_pencils", small, dim3(resident_blocks(small, PC_L7B_TPB_SMALL, &small_grid)), dim3(PC_L7B_TPB_SMALL), s, w.tmp, d_sorted, w.pencil_start, table,
+              w.big_count, w.big_list, first_pencil, end_pencil, 0u, (uint32_t)PC_L7B_CAP_SMALL, d_status);
+    PC_LAUNCH("pc_l7b_sort_big_pencils", large, dim3(resident_blocks(large, PC_L7B_TPB_LARGE, &large_grid)), dim3(PC_L7B_TPB_LARGE), s, w.tmp, d_sorted, w.pencil_start, table,
+              w.big_count, w.big_list, first_pencil, end_pencil, (uint32_t)PC_L7B_CAP_SMALL, 0xFFFFFFFFu, d_status);
     PC_HIP(hipGetLastError());
     return PC_OK;
 }

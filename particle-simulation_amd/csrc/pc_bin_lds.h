@@ -414,19 +414,25 @@ pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
 
 // ---- L7B: one workgroup sorts one big pencil ------------------------------------
 // Pencils with more points than a wave of L7 keeps (clustered inputs, or more than
-// about 15 points per cell everywhere) are listed by L5.  Up to PC_L7B_CAP points
-// go through registers and an LDS copy in cell order like L7's; beyond that the
-// pencil is read twice (histogram, then scatter through LDS cursors).
-#define PC_L7B_TPB 512
-#define PC_L7B_CAP 8192
-#define PC_L7B_PPT (PC_L7B_CAP / PC_L7B_TPB)
+// about 2 points per cell everywhere) are listed by L5.  Up to CAP points go
+// through registers and an LDS copy in cell order like L7's; beyond that the
+// pencil is read twice (histogram, then scatter through LDS cursors).  Two
+// instantiations share the list: a small one (several workgroups per CU) takes
+// the pencils of at most PC_L7B_CAP_SMALL points, a large one the rest.
+#define PC_L7B_CAP_SMALL 2048
+#define PC_L7B_TPB_SMALL 256
+#define PC_L7B_CAP_LARGE 8192
+#define PC_L7B_TPB_LARGE 512
 
+template <int PC_L7B_CAP, int PC_L7B_TPB>
 __global__ void __launch_bounds__(PC_L7B_TPB)
 pc_l7b_sort_big_pencils(const float *__restrict__ src, float *__restrict__ dst,
                         const uint32_t *__restrict__ pencil_start, uint32_t *__restrict__ table,
                         const uint32_t *__restrict__ big_count, const uint32_t *__restrict__ big_list,
-                        uint32_t first_pencil, uint32_t end_pencil, int32_t *__restrict__ status)
+                        uint32_t first_pencil, uint32_t end_pencil, uint32_t n_above, uint32_t n_upto,
+                        int32_t *__restrict__ status)
 {
+    constexpr int PC_L7B_PPT = PC_L7B_CAP / PC_L7B_TPB;
     __shared__ uint32_t hist[PC_L_BINS];
     __shared__ float stage[PC_L7B_CAP * 3];
     const int tid = threadIdx.x;
@@ -436,6 +442,7 @@ pc_l7b_sort_big_pencils(const float *__restrict__ src, float *__restrict__ dst,
         const uint32_t pencil = big_list[b];
         if (pencil < first_pencil || pencil >= end_pencil) continue;          // workgroup-uniform
         const uint32_t base = pencil_start[pencil], n = pencil_start[pencil + 1] - base;
+        if (n <= n_above || n > n_upto) continue;                             // the other instantiation's
         uint32_t *slice = table + (uint64_t)pencil * PC_NBB;
         const pc_pt3 *g = reinterpret_cast<const pc_pt3 *>(src) + base;
         __syncthreads();                                                     // previous pencil's LDS reads are done
