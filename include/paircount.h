@@ -143,8 +143,10 @@ int pc_count_pairs_device(const float *d_xyz, uint64_t n, int x_lo, int x_hi,
                           uint64_t *d_npairs, int32_t *d_status, void *stream);
 
 /* Selects kernel variants (for A/B measurement and cross-checks); values are
-   documented next to the kernels.  name: "bin" | "count".  Returns PC_ERR_ARG
-   for an unknown name or value. */
+   documented next to the kernels.  name: "bin" | "count", or "segments": the
+   capacity of the pair test's list of heavy-pencil segments (default and
+   maximum 262144; 0 = never cut a pencil).  Returns PC_ERR_ARG for an unknown
+   name or value. */
 int pc_set_variant(const char *name, int value);
 
 /* Per-kernel device timing for the stage functions above: while enabled, a

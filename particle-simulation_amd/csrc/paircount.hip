@@ -42,6 +42,7 @@ extern "C" const char *pc_version(void) { return "1.0 gfx950"; }
 // ---------------------------------------------------------------- variants --
 static int g_variant_bin = 1;     // 0 = atomic counting sort, 1 = LDS-staged three-level bucket sort
 static int g_variant_count = 3;   // 0 = global memory, 1 = LDS-tiled strips, 2 = wave per pencil, 3 = candidate-parallel groups
+static int g_segments = PC_G_SEG_CAP;   // capacity of the heavy-pencil segment list (0: pencils are never cut)
 
 extern "C" int pc_set_variant(const char *name, int value)
 {
@@ -54,6 +55,11 @@ extern "C" int pc_set_variant(const char *name, int value)
     if (!strcmp(name, "count")) {
         if (value < 0 || value > 3) return pc_fail(PC_ERR_ARG, "pc_set_variant: count variant %d unknown", value);
         g_variant_count = value;
+        return PC_OK;
+    }
+    if (!strcmp(name, "segments")) {
+        if (value < 0 || value > PC_G_SEG_CAP) return pc_fail(PC_ERR_ARG, "pc_set_variant: segment capacity %d not in [0,%d]", value, PC_G_SEG_CAP);
+        g_segments = value;
         return PC_OK;
     }
     return pc_fail(PC_ERR_ARG, "pc_set_variant: unknown name '%s'", name);
@@ -380,7 +386,8 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
         if (rc2) return rc2;
         PC_HIP(hipMemsetAsync(queue, 0, PC_G_FLAGS * sizeof(unsigned int), (hipStream_t)stream));   // all counters
         const dim3 plan_grid(((x_hi - x_lo) * PC_NLAYERS + 255) / 256);
-        PC_LAUNCH("pc_c3_plan", pc_c3_plan, plan_grid, dim3(256), (hipStream_t)stream, d_cell_start, x_lo, x_hi, queue);
+        PC_LAUNCH("pc_c3_plan", pc_c3_plan, plan_grid, dim3(256), (hipStream_t)stream, d_cell_start, x_lo, x_hi, queue,
+                  (uint32_t)g_segments);
         // as many workgroups as are resident at once (registers and LDS decide: asked of the runtime, once)
         static int resident_on[64];               // per device ordinal (count_queue has checked the range)
         int dev = 0;
@@ -397,7 +404,7 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
         const int want = resident, most = ((x_hi - x_lo) * PC_NLAYERS + PC_G_WAVES - 1) / PC_G_WAVES;
         const int grid = ((want < most ? want : most) + 7) / 8 * 8;
         PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
-                  d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, (unsigned long long *)d_npairs);
+                  d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, (uint32_t)g_segments, (unsigned long long *)d_npairs);
     } else if (g_variant_count == 2) {
         const int grid = 8 * (x_hi - x_lo) * PC_W_WG_PER_BAND;
         PC_LAUNCH("pc_c2_count_waves", pc_c2_count_waves, dim3(grid), dim3(PC_W_WAVES * 64), (hipStream_t)stream,

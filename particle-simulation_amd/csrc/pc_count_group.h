@@ -327,7 +327,7 @@ __device__ __forceinline__ uint32_t pc_plan_walk(const uint32_t *__restrict__ ro
 }
 
 __global__ void __launch_bounds__(256)
-pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__restrict__ work)
+pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__restrict__ work, uint32_t seg_cap)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= (x_hi - x_lo) * PC_NLAYERS) return;
@@ -340,12 +340,12 @@ pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__r
         const uint32_t segs = pc_plan_walk<false>(row, pencil, work, 0, target);
         if (segs >= 2) {
             const uint32_t at = atomicAdd(work + PC_G_SEG_COUNT, segs);
-            if (at + segs <= PC_G_SEG_CAP) {
+            if (at + segs <= seg_cap) {
                 pc_plan_walk<true>(row, pencil, work, at, target);
                 planned = 1;
             } else {
                 // the list is full: the pencil stays whole, the slots it reserved below the cap stay empty
-                for (uint32_t q = at; q < PC_G_SEG_CAP; q++) work[PC_G_SEGS + 2 * q] = 0;
+                for (uint32_t q = at; q < seg_cap; q++) work[PC_G_SEGS + 2 * q] = 0;
             }
         }
     }
@@ -354,7 +354,7 @@ pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__r
 
 __global__ void __launch_bounds__(PC_G_WAVES * 64, 4)   // registers and LDS admit 5 waves per SIMD
 pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T, int x_lo, int x_hi,
-                   unsigned int *__restrict__ queue, unsigned long long *__restrict__ out)
+                   unsigned int *__restrict__ queue, uint32_t seg_cap, unsigned long long *__restrict__ out)
 {
     __shared__ pc_group_lds lds_all[PC_G_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -393,7 +393,7 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
             }
             if (m >= band_pencils) {
                 segment_phase = true;
-                n_segments = (int)min(__builtin_amdgcn_readfirstlane(queue[PC_G_SEG_COUNT]), (uint32_t)PC_G_SEG_CAP);
+                n_segments = (int)min(__builtin_amdgcn_readfirstlane(queue[PC_G_SEG_COUNT]), seg_cap);
                 if (lane == 0) m = (int)atomicAdd(queue + PC_G_SEG_DRAW, 1u);
                 m = __builtin_amdgcn_readfirstlane(m);
                 continue;

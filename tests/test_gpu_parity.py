@@ -307,3 +307,27 @@ def test_two_contexts_finish_concurrently(psa, torch_mod, oracle):
         [t.join() for t in th]
         assert got == want
         [pc.close() for pc in pcs]
+
+
+def test_segment_list_overflow(psa, stages, torch_mod, oracle):
+    """Heavy pencils are cut into segments by a planning kernel; when the segment
+    list is too small for all of them the rest must be counted whole, slots
+    reserved by a pencil that did not fit must be skipped, and capacity 0 must
+    switch the mechanism off -- same count every time."""
+    rng = np.random.default_rng(5)
+    # six heavy pencils of different weight next to each other, plus background
+    parts = [rng.uniform(-9.999, 9.999, (50_000, 3))]
+    for q, npts in enumerate((3000, 9000, 20000, 5000, 40000, 2500)):
+        parts.append(_cell_box(rng, npts, (120, 200 + q, 0), (121, 201 + q, 400)))
+    xyz = np.concatenate(parts).astype(np.float32)
+    want, want_tests = oracle.count_pairs(xyz)
+    try:
+        for cap in (262144, 0, 1, 3, 7, 16, 40, 1000):
+            psa.set_variant("segments", cap)
+            got, tests, _ = gpu_count(psa, stages, torch_mod, xyz)
+            assert got == want, cap
+            assert tests == want_tests
+        with pytest.raises(psa.PairCountError):
+            psa.set_variant("segments", 262145)
+    finally:
+        psa.set_variant("segments", 262144)
