@@ -488,7 +488,24 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                     // ---- merged copy of rows 1-4, in two stages.  Stage 1, lane t = cell t:
                     //      write the sorted-array slot of each of the cell's points to the
                     //      gather list, row after row (they land at ex_m + 0..nm-1).
-                    {
+                    //      A window of at most 16 cells (dense data: many points per cell, so each
+                    //      of the loops below would run long on a few lanes) is spread over all
+                    //      lanes instead: lane = (cell, row) writes that row's part of the cell.
+                    const bool few_cells = t_last < 16;
+                    if (few_cells) {
+                        const int tc = lane >> 2, rr = lane & 3;
+                        const uint32_t off[4] = {ex_m, ex_m + n[1], ex_m + n[1] + n[2], ex_m + n[1] + n[2] + n[3]};
+                        uint32_t sv = 0, nv = 0, ov = 0;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const uint32_t a = __shfl(s[1 + r], tc, 64), b = __shfl(n[1 + r], tc, 64), c = __shfl(off[r], tc, 64);
+                            if (rr == r) { sv = a; nv = b; ov = c; }
+                        }
+                        if (tc > t_last) nv = 0;
+                        for (uint32_t v = 0; __builtin_amdgcn_ballot_w64(v < nv) != 0; v++)
+                            if (v < nv) L.src[ov + v] = sv + v;
+                        if (lane <= t_last && (nm_pts & 1)) L.src[ex_m + nm_pts] = home_lo;   // the pad slot copies any valid point ...
+                    } else {
                         uint32_t o = ex_m;
 #pragma unroll
                         for (int r = 1; r < 5; r++) {
@@ -518,7 +535,13 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                                          L.hx + 64 * qq, L.hy + 64 * qq, L.hz + 64 * qq);
                     }
                     // ---- per home particle: its merged candidate range and the end of its row-0 range
-                    if (lane >= th0 && lane < t_last) {
+                    if (few_cells) {                           // four lanes per cell, every fourth particle each
+                        const int tc = lane >> 2;
+                        const uint32_t word = __shfl(lo_m | (hi_m << 16), tc, 64), end0 = __shfl(hi_h, tc, 64);
+                        const uint32_t first = __shfl(ex_h, tc, 64), in_cell = __shfl(n[0], tc, 64);    // (every lane takes part in the exchange)
+                        const uint32_t count = (tc >= th0 && tc < t_last) ? in_cell : 0u;
+                        for (uint32_t u = lane & 3; u < count; u += 4) L.meta[first + u] = make_uint2(word, end0);
+                    } else if (lane >= th0 && lane < t_last) {
                         for (uint32_t u = 0; u < n[0]; u++) L.meta[ex_h + u] = make_uint2(lo_m | (hi_m << 16), hi_h);
                     }
                     pc_dma_wait();
@@ -548,7 +571,7 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                         for (uint32_t hp = lane; hp < nh; hp += 64) {
                             const float mx = L.hx[hp], my = L.hy[hp], mz = L.hz[hp];
                             const pc_v2f ax = {mx, mx}, ay = {my, my}, az = {mz, mz};
-                            const uint32_t end = L.meta[hp].y;
+                            const uint32_t end = min(L.meta[hp].y, (uint32_t)PC_G_CAPH);    // (an index into the row-0 arrays)
                             uint32_t cnt = 0;
                             for (uint32_t k2 = hp + 1; k2 < end; k2 += 2) {       // two candidates per turn
                                 const pc_v2f x = {L.hx[k2], L.hx[k2 + 1]}, y = {L.hy[k2], L.hy[k2 + 1]}, z = {L.hz[k2], L.hz[k2 + 1]};
