@@ -5,7 +5,7 @@
 
 One step = one pass of the hot path (cell keys, binning, pair test, and for
 N > 1 the 8-byte all-reduce) over synthetic points already resident in HBM.
-Workloads (BASELINE.json configs): uniform100m (default: the configuration the
+Workloads (the configurations of the task): uniform100m (default: the configuration the
 metric is quoted on), uniform10m, blobs100m, uniform1b (125 M points per GPU,
 weak scaling).  For N > 1 the x range is cut into N slabs, one rank per GPU;
 each rank holds its slab's points plus the +x halo layer.
