@@ -115,7 +115,7 @@ def main():
     if slabs > 1 and kind_name == "blobs":
         # clustered input: cut where the estimated pair-test cost (layer population squared) balances
         pop = ht.layer_histogram(kind, args.seed, total_points, sigma,
-                                 threads=max(1, ht.host_threads() // min(world, 8))).astype(np.float64)
+                                 threads=max(1, min(16, (os.cpu_count() or 1) // max(world, 1)))).astype(np.float64)
         cuts = sh.balanced_cuts(pop * pop, slabs)
     else:
         cuts = sh.equal_cuts(slabs)
@@ -127,7 +127,12 @@ def main():
 
     # ---- synthetic input: this rank's slab plus its +x halo layer, resident in HBM ----
     t_gen = time.time()
-    threads = max(1, ht.host_threads() // min(world, 8)) if world > 1 else ht.host_threads()
+    # generator threads of this rank: its share of the CPUs this job may use, at most 16
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 1
+    threads = max(1, min(16, cpus // world))
     if slabs == 1:
         host = ht.generate(kind, args.seed, total_points, sigma, threads=threads)
     else:
