@@ -41,7 +41,9 @@ extern "C" const char *pc_version(void) { return "1.0 gfx950"; }
 
 // ---------------------------------------------------------------- variants --
 static int g_variant_bin = 1;     // 0 = atomic counting sort, 1 = LDS-staged three-level bucket sort
-static int g_variant_count = 3;   // 0 = global memory, 1 = LDS-tiled strips, 2 = wave per pencil, 3 = candidate-parallel groups
+// 0 = global memory, 1 = LDS-tiled strips, 2 = wave per pencil, 3 = candidate-parallel groups,
+// 4 = by density: 0 below 0.8 points per cell of the slab on average, else 3
+static int g_variant_count = 4;
 static int g_segments = PC_G_SEG_CAP;   // capacity of the heavy-pencil segment list (0: pencils are never cut)
 
 extern "C" int pc_set_variant(const char *name, int value)
@@ -53,7 +55,7 @@ extern "C" int pc_set_variant(const char *name, int value)
         return PC_OK;
     }
     if (!strcmp(name, "count")) {
-        if (value < 0 || value > 3) return pc_fail(PC_ERR_ARG, "pc_set_variant: count variant %d unknown", value);
+        if (value < 0 || value > 4) return pc_fail(PC_ERR_ARG, "pc_set_variant: count variant %d unknown", value);
         g_variant_count = value;
         return PC_OK;
     }
@@ -374,11 +376,18 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
     int rc = check_slab("pc_count_sorted_device", x_lo, x_hi);
     if (rc) return rc;
     if (n == 0 || x_lo == x_hi) return PC_OK;
-    if (g_variant_count == 0) {
+    int variant = g_variant_count;
+    if (variant == 4) {
+        // Sparse inputs: a window of 64 cells holds too few particles to pay for its bookkeeping, and the
+        // thread-per-particle kernel wins (measured crossover at 55 M uniform points = 0.86 per cell).
+        const uint64_t cells = (uint64_t)(x_hi < PC_NLAYERS ? x_hi - x_lo + 1 : x_hi - x_lo) * PC_NLAYERS * PC_NLAYERS;
+        variant = n * 5 < cells * 4 ? 0 : 3;
+    }
+    if (variant == 0) {
         uint32_t c_lo = (uint32_t)x_lo * PC_NBB2, c_hi = (uint32_t)x_hi * PC_NBB2;
-        PC_LAUNCH("pc_c0_count_global", pc_c0_count_global, dim3(grid_for(n, 256, 1 << 20)), dim3(256), (hipStream_t)stream, d_sorted_xyz, d_cell_start, c_lo, c_hi,
+        PC_LAUNCH("pc_c0_count_global", pc_c0_count_global, dim3(grid_for(n, 256, 4096)), dim3(256), (hipStream_t)stream, d_sorted_xyz, d_cell_start, c_lo, c_hi,
                            (unsigned long long *)d_npairs);
-    } else if (g_variant_count == 3) {
+    } else if (variant == 3) {
         // persistent: one resident set of waves, never more waves than pencils;
         // the eight work counters are zeroed on the stream ahead of the launch
         unsigned int *queue = nullptr;
@@ -405,7 +414,7 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
         const int grid = ((want < most ? want : most) + 7) / 8 * 8;
         PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
                   d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, (uint32_t)g_segments, (unsigned long long *)d_npairs);
-    } else if (g_variant_count == 2) {
+    } else if (variant == 2) {
         const int grid = 8 * (x_hi - x_lo) * PC_W_WG_PER_BAND;
         PC_LAUNCH("pc_c2_count_waves", pc_c2_count_waves, dim3(grid), dim3(PC_W_WAVES * 64), (hipStream_t)stream,
                   d_sorted_xyz, d_cell_start, x_lo, x_hi, (unsigned long long *)d_npairs);

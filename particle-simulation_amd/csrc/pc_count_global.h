@@ -5,8 +5,11 @@
 //   c+1 | c+402..c+404 | c+162005..c+162007 | c+162408..c+162410 | c+162811..c+162813
 // (offsets of main.c:195-209; the 403-wide padding keeps face aliasing empty),
 // and "later points of the same cell" are the sorted slots after the home
-// particle.  Efficient only when a wave's lanes share candidates (dense cells);
-// the cross-check for the LDS-tiled variant.  pc_set_variant("count", 0).
+// particle.  No staging and no per-window bookkeeping: the fastest form for sparse
+// inputs (below about 0.9 points per cell), where it is the default, and the
+// cross-check for the staged variants elsewhere.  pc_set_variant("count", 0).
+// The grid is capped by the host (grid-stride loop): every workgroup ends with
+// one atomic on the same address, and those serialise.
 #pragma once
 #include "pc_device.h"
 
@@ -20,20 +23,29 @@ pc_c0_count_global(const float *__restrict__ pts, const uint32_t *__restrict__ T
     uint32_t stride = gridDim.x * blockDim.x;
     for (uint64_t p64 = (uint64_t)first + blockIdx.x * blockDim.x + threadIdx.x; p64 < last; p64 += stride) {
         uint32_t p = (uint32_t)p64;
-        float x = pts[3 * (uint64_t)p], y = pts[3 * (uint64_t)p + 1], z = pts[3 * (uint64_t)p + 2];
+        struct pt3 { float x, y, z; };                 // one 12-byte load per point
+        const pt3 *P = reinterpret_cast<const pt3 *>(pts);
+        const pt3 me = P[p];
+        const float x = me.x, y = me.y, z = me.z;
         uint32_t c = pc_key(pc_cell_index(x), pc_cell_index(y), pc_cell_index(z));
         uint32_t cnt = 0;
-        // same cell (later slots) and cell c+1: slots (p, T[c+2])
-        uint32_t lo = p + 1, hi = T[c + 2];
-        for (uint32_t q = lo; q < hi; q++)
-            cnt += pc_hit(x, y, z, pts[3 * (uint64_t)q], pts[3 * (uint64_t)q + 1], pts[3 * (uint64_t)q + 2]);
-        const uint32_t base[4] = {402u, 162005u, 162408u, 162811u};
+        // the five candidate ranges: same cell (later slots) with cell c+1 = slots (p, T[c+2]), then the
+        // three-cell runs of the four neighbour pencils; all ten table reads are issued before any is used
+        const uint32_t base[5] = {0u, 402u, 162005u, 162408u, 162811u};
+        uint32_t lo[5], hi[5];
+        lo[0] = p + 1;
+        hi[0] = T[c + 2];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            lo = T[c + base[r]];
-            hi = T[c + base[r] + 3];
-            for (uint32_t q = lo; q < hi; q++)
-                cnt += pc_hit(x, y, z, pts[3 * (uint64_t)q], pts[3 * (uint64_t)q + 1], pts[3 * (uint64_t)q + 2]);
+        for (int r = 1; r < 5; r++) {
+            lo[r] = T[c + base[r]];
+            hi[r] = T[c + base[r] + 3];
+        }
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            for (uint32_t q = lo[r]; q < hi[r]; q++) {
+                const pt3 v = P[q];
+                cnt += pc_hit(x, y, z, v.x, v.y, v.z);
+            }
         }
         acc += cnt;
     }

@@ -23,14 +23,24 @@ def stages(psa, torch_mod):
     return psa.DeviceStages(2_100_000, "cuda:0")
 
 
+@pytest.fixture(autouse=True)
+def default_variants(psa):
+    """Every test starts and ends on the library's default kernels."""
+    psa.set_variant("bin", 1)
+    psa.set_variant("count", 4)
+    yield
+    psa.set_variant("bin", 1)
+    psa.set_variant("count", 4)
+
+
 def dev(torch_mod, a):
     return torch_mod.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to("cuda:0")
 
 
-VARIANTS = [(1, 3), (0, 0), (1, 1), (0, 2)]      # (binning variant, pair-test variant)
+VARIANTS = [(1, 4), (1, 3), (0, 0), (1, 1), (0, 2)]      # (binning variant, pair-test variant; 4 = chosen by density)
 
 
-def gpu_count(psa, stages, torch_mod, xyz, x_lo=0, x_hi=400, bin_v=1, count_v=3):
+def gpu_count(psa, stages, torch_mod, xyz, x_lo=0, x_hi=400, bin_v=1, count_v=4):
     psa.set_variant("bin", bin_v)
     psa.set_variant("count", count_v)
     t = dev(torch_mod, xyz).reshape(-1, 3)
@@ -294,6 +304,7 @@ def test_two_contexts_finish_concurrently(psa, torch_mod, oracle):
     sets = [rng.uniform(-2.0, 2.0, (250_000, 3)).astype(np.float32),
             _cell_box(rng, 30_000, (50, 60, 0), (51, 61, 400)).astype(np.float32)]   # the second one has planned segments
     want = [oracle.count_pairs(x)[0] for x in sets]
+    psa.set_variant("count", 3)                 # the variant with the per-device work area
     for _ in range(3):
         pcs = [psa.PairCounter(device=0, expected_points=len(x)) for x in sets]
         for pc, x in zip(pcs, sets):
@@ -324,7 +335,7 @@ def test_segment_list_overflow(psa, stages, torch_mod, oracle):
     try:
         for cap in (262144, 0, 1, 3, 7, 16, 40, 1000):
             psa.set_variant("segments", cap)
-            got, tests, _ = gpu_count(psa, stages, torch_mod, xyz)
+            got, tests, _ = gpu_count(psa, stages, torch_mod, xyz, count_v=3)      # (by density this input would take variant 0)
             assert got == want, cap
             assert tests == want_tests
         with pytest.raises(psa.PairCountError):
