@@ -60,6 +60,11 @@ def build_hip(force=False):
         bad = [ln.strip() for ln in f if FUSED_F32.search(ln)]
     if bad:
         raise RuntimeError("fused f32 multiply-add in device code (breaks bit-exact parity):\n" + "\n".join(bad[:10]))
+    # the pair-test kernel runs five waves per SIMD only up to 96 vector registers; one more costs a wave (3 % of its time)
+    with open(asm) as f:
+        m = re.search(r"\.set _Z18pc_c3_count_groups\w*\.num_vgpr, (\d+)", f.read())
+    if m and int(m.group(1)) > 96:
+        raise RuntimeError("pc_c3_count_groups uses %s vector registers (> 96: four waves per SIMD instead of five)" % m.group(1))
     _run([HIPCC] + HIP_FLAGS + ["-shared", "-o", out, main_src, "-lpthread"])
     return out
 

@@ -500,6 +500,8 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                         for (int r = 0; r < 4; r++) {
                             const uint32_t a = __shfl(s[1 + r], tc, 64), b = __shfl(n[1 + r], tc, 64), c = __shfl(off[r], tc, 64);
                             if (rr == r) { sv = a; nv = b; ov = c; }
+                            // one row's exchange at a time: all twelve in flight would cost the kernel a wave per SIMD in registers
+                            asm volatile("" : "+v"(sv), "+v"(nv), "+v"(ov));
                         }
                         if (tc > t_last) nv = 0;
                         for (uint32_t v = 0; __builtin_amdgcn_ballot_w64(v < nv) != 0; v++)
@@ -535,13 +537,8 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                                          L.hx + 64 * qq, L.hy + 64 * qq, L.hz + 64 * qq);
                     }
                     // ---- per home particle: its merged candidate range and the end of its row-0 range
-                    if (few_cells) {                           // four lanes per cell, every fourth particle each
-                        const int tc = lane >> 2;
-                        const uint32_t word = __shfl(lo_m | (hi_m << 16), tc, 64), end0 = __shfl(hi_h, tc, 64);
-                        const uint32_t first = __shfl(ex_h, tc, 64), in_cell = __shfl(n[0], tc, 64);    // (every lane takes part in the exchange)
-                        const uint32_t count = (tc >= th0 && tc < t_last) ? in_cell : 0u;
-                        for (uint32_t u = lane & 3; u < count; u += 4) L.meta[first + u] = make_uint2(word, end0);
-                    } else if (lane >= th0 && lane < t_last) {
+                    // (spreading these writes over four lanes per cell as well costs ten registers, i.e. the fifth wave per SIMD)
+                    if (lane >= th0 && lane < t_last) {
                         for (uint32_t u = 0; u < n[0]; u++) L.meta[ex_h + u] = make_uint2(lo_m | (hi_m << 16), hi_h);
                     }
                     pc_dma_wait();
