@@ -64,7 +64,8 @@ def build_hip(force=False):
     with open(asm) as f:
         m = re.search(r"\.set _Z18pc_c3_count_groups\w*\.num_vgpr, (\d+)", f.read())
     if m and int(m.group(1)) > 96:
-        raise RuntimeError("pc_c3_count_groups uses %s vector registers (> 96: four waves per SIMD instead of five)" % m.group(1))
+        print("warning: pc_c3_count_groups uses %s vector registers (> 96: four waves per SIMD instead of five)" % m.group(1),
+              file=sys.stderr)
     _run([HIPCC] + HIP_FLAGS + ["-shared", "-o", out, main_src, "-lpthread"])
     return out
 
