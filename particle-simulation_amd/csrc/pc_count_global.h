@@ -40,11 +40,17 @@ pc_c0_count_global(const float *__restrict__ pts, const uint32_t *__restrict__ T
             lo[r] = T[c + base[r]];
             hi[r] = T[c + base[r] + 3];
         }
+        // two candidates per turn, packed arithmetic (v_pk_add/mul_f32); the second one of an odd tail is masked
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f ax = {x, x}, ay = {y, y}, az = {z, z};
 #pragma unroll
         for (int r = 0; r < 5; r++) {
-            for (uint32_t q = lo[r]; q < hi[r]; q++) {
-                const pt3 v = P[q];
-                cnt += pc_hit(x, y, z, v.x, v.y, v.z);
+            for (uint32_t q = lo[r]; q < hi[r]; q += 2) {
+                const pt3 v0 = P[q], v1 = P[min(q + 1, hi[r] - 1)];
+                const v2f cx = {v0.x, v1.x}, cy = {v0.y, v1.y}, cz = {v0.z, v1.z};
+                const v2f dx = ax - cx, dy = ay - cy, dz = az - cz;
+                const v2f sq = (dx * dx + dy * dy) + dz * dz;            // unfused: see the build flags
+                cnt += (sq.x <= 0.0025f) + ((sq.y <= 0.0025f) & (q + 1 < hi[r]));
             }
         }
         acc += cnt;
