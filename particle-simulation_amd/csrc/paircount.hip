@@ -437,7 +437,7 @@ extern "C" int pc_count_tests_device(const uint32_t *d_cell_start, int x_lo, int
     if (rc) return rc;
     if (x_lo == x_hi) return PC_OK;
     uint32_t c_lo = (uint32_t)x_lo * PC_NBB2, c_hi = (uint32_t)x_hi * PC_NBB2;
-    PC_LAUNCH("pc_count_tests", pc_count_tests, dim3(8192), dim3(256), (hipStream_t)stream, d_cell_start, c_lo,
+    PC_LAUNCH("pc_count_tests", pc_count_tests, dim3(2048), dim3(256), (hipStream_t)stream, d_cell_start, c_lo,
                        c_hi, (unsigned long long *)d_ntests);
     PC_HIP(hipGetLastError());
     return PC_OK;
