@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""One GPU, N points (default 1e9 uniform: the whole 1 B configuration on a single MI355X).
+
+No oracle finishes at this size, so the result is checked through independent
+routes to the same integers: the candidate-parallel pair test against the
+thread-per-particle kernel, the LDS bucket sort's table against the
+atomic-scatter binning's, and the whole-domain count against the sum over four
+x slabs that each hold only their own points plus the halo layer.
+
+    python tools/big_single_gpu.py [--points N] [--out FILE]
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def say(*a):
+    print(*a, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=1_000_000_000)
+    ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    import torch
+    from __graft_entry__ import load_package
+    psa = load_package()
+    ht = importlib.import_module("particle_simulation_amd.hosttools")
+    NBB = 403
+    n = args.points
+    t0 = time.time()
+    chunks, done, piece = [], 0, 125_000_000
+    while done < n:                       # the generator's stream is positional: piece by piece
+        m = min(piece, n - done)
+        part = ht.generate(ht.UNIFORM, args.seed, m, 0, first=done, threads=16)
+        chunks.append(torch.from_numpy(part).to("cuda:0"))
+        done += part.shape[0]
+        say("generated %d points, %.1f s" % (done, time.time() - t0))
+        del part
+    xyz = torch.cat(chunks)
+    del chunks
+    assert xyz.shape[0] == n, (xyz.shape, n)
+    say("resident: %d points, %.1f GB" % (n, xyz.numel() * 4 / 1e9))
+
+    st = psa.DeviceStages(n, "cuda:0")
+    res = {"points": n}
+
+    def timed(fn, reps=3):
+        best = 1e30
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t = time.time()
+            fn()
+            torch.cuda.synchronize()
+            best = min(best, time.time() - t)
+        return best * 1e3
+
+    psa.set_variant("bin", 1)
+    psa.set_variant("count", 4)
+    res["step_ms"] = timed(lambda: st.count_pairs(xyz))
+    whole = st.pairs()
+    st.count_tests()
+    tests = st.tests()
+    res.update(pairs=whole, tests=tests, tests_per_s=tests / (res["step_ms"] * 1e-3))
+    say("whole domain: %d pairs, %d tests, %.1f ms per step" % (whole, tests, res["step_ms"]))
+    table = st.table[: NBB ** 3 + 1].clone()
+    assert int(table[-1].item()) == n
+    assert bool((table[1:] >= table[:-1]).all())
+
+    # the other pair-test kernel on the same sorted array
+    psa.set_variant("count", 0)
+    res["thread_per_particle_ms"] = timed(lambda: st.count_sorted(n), reps=1)
+    res["thread_per_particle_pairs"] = st.pairs()
+    say("thread-per-particle kernel: %d pairs, %.1f ms" % (st.pairs(), res["thread_per_particle_ms"]))
+    assert st.pairs() == whole
+    psa.set_variant("count", 4)
+
+    # four slabs, own points + halo only
+    srt = st.sorted[:n].clone()
+    total = total_tests = 0
+    slab_cuts = [0, 100, 200, 300, 400]
+    for lo, hi in zip(slab_cuts[:-1], slab_cuts[1:]):
+        a = int(table[lo * NBB * NBB].item())
+        b = int(table[min(hi + 1, NBB) * NBB * NBB].item())
+        part = srt[a:b].contiguous()
+        st.count_pairs(part, lo, hi)
+        st.count_tests(lo, hi)
+        total += st.pairs()
+        total_tests += st.tests()
+        say("slab [%d,%d): %d points held, running total %d pairs" % (lo, hi, b - a, total))
+        del part
+    res.update(slab_sum_pairs=total, slab_sum_tests=total_tests)
+    assert total == whole and total_tests == tests
+    del srt
+
+    # atomic-scatter binning builds the same table
+    psa.set_variant("bin", 0)
+    res["atomic_binning_ms"] = timed(lambda: st.bin(xyz), reps=1)
+    same = bool((st.table[: NBB ** 3 + 1] == table).all())
+    res["tables_equal"] = same
+    say("atomic-scatter binning: %.1f ms, table equal: %s" % (res["atomic_binning_ms"], same))
+    assert same
+    psa.set_variant("bin", 1)
+    res["ok"] = True
+    line = json.dumps(res)
+    say(line)
+    if args.out:
+        with open(args.out, "w") as f:
+            f.write(line + "\n")
+
+
+if __name__ == "__main__":
+    main()
