@@ -71,7 +71,10 @@ def main():
     tests = st.tests()
     res.update(pairs=whole, tests=tests, tests_per_s=tests / (res["step_ms"] * 1e-3))
     say("whole domain: %d pairs, %d tests, %.1f ms per step" % (whole, tests, res["step_ms"]))
-    table = st.table[: NBB ** 3 + 1].clone()
+    def table_u32():                      # the table holds uint32 slots; torch shows them as int32
+        return st.table[: NBB ** 3 + 1].to(torch.int64) & 0xFFFFFFFF
+
+    table = table_u32()
     assert int(table[-1].item()) == n
     assert bool((table[1:] >= table[:-1]).all())
 
@@ -104,7 +107,7 @@ def main():
     # atomic-scatter binning builds the same table
     psa.set_variant("bin", 0)
     res["atomic_binning_ms"] = timed(lambda: st.bin(xyz), reps=1)
-    same = bool((st.table[: NBB ** 3 + 1] == table).all())
+    same = bool((table_u32() == table).all())
     res["tables_equal"] = same
     say("atomic-scatter binning: %.1f ms, table equal: %s" % (res["atomic_binning_ms"], same))
     assert same
