@@ -49,7 +49,7 @@ static void *parser_thread(void *arg)
     uint64_t n = 0;
     while (p < stop) {
         int err = 0;
-        p = xyz_parse_line(p, block + 3 * n, &err);
+        p = xyz_parse_line_bounded(p, w->file + w->size, block + 3 * n, &err);
         if (err) {
             w->status = 1;
             snprintf(w->msg, sizeof w->msg, err == XYZ_ERR_NODOT ? "*str != '.'" : "sci_exp > 0");

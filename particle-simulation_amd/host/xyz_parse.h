@@ -89,6 +89,76 @@ static inline uint32_t xyz_parse_float_bits(const char *tok, const char **end, i
     return ((uint32_t)neg << 31) | ((uint32_t)((e2 + 127) & 0xFF) << 23) | (mant & 0x7FFFFFu);
 }
 
+/* ---- short cut for the common token shape "[-]d.dddddd" ------------------------
+ * Same result as xyz_parse_float_bits, computed without per-character loops: the
+ * eight characters are checked and converted as one 64-bit word, the leading-zero
+ * scan is a count of trailing zero bytes, and the truncating divisions by 5^k use
+ * a reciprocal with one correction step (exact).  Anything else -- other digit
+ * counts, an exponent, a missing '.', fewer than XYZ_FAST_BYTES readable bytes --
+ * goes to the general function.  The caller guarantees tok[0..XYZ_FAST_BYTES) is
+ * readable. */
+#define XYZ_FAST_BYTES 10           /* sign + 8 characters + the terminator */
+
+/* floor(2^64 / 5^k), k = 0..6 (entry 0 unused) */
+static const uint64_t xyz_recip5[7] = {
+    0ull, 3689348814741910323ull, 737869762948382064ull, 147573952589676412ull,
+    29514790517935282ull, 5902958103587056ull, 1180591620717411ull};
+
+/* floor(m / 5^k) for 1 <= k <= 6 */
+static inline uint64_t xyz_div_pow5(uint64_t m, int k)
+{
+    const uint64_t d = xyz_pow5[k];
+    uint64_t q = (uint64_t)(((unsigned __int128)m * xyz_recip5[k]) >> 64);   /* floor(m/d) or one less */
+    q += (m - q * d >= d);
+    return q;
+}
+
+static inline uint32_t xyz_parse_float_bits_fast(const char *tok, const char **end, int *err)
+{
+    static const int8_t log2_digit[10] = {0, 0, 1, 1, 2, 2, 2, 2, 3, 3};
+    const int neg = (*tok == '-');
+    const char *p = tok + neg;
+    uint64_t w;
+    memcpy(&w, p, 8);
+    /* little endian: byte 0 = first character.  x has digit values where digits are expected, 0 for the '.' */
+    const uint64_t x = w ^ 0x3030303030302E30ull;
+    const int shape_ok = ((((x + 0x7676767676767676ull) | x) & 0x8080808080808080ull) == 0) &   /* every byte <= 9 */
+                         ((x & 0xFF00u) == 0) &                                              /* '.' in place */
+                         ((unsigned char)p[8] <= ' ');                                       /* blank or control character next */
+    if (__builtin_expect(!shape_ok, 0)) return xyz_parse_float_bits(tok, end, err);
+    *end = p + 8;
+    *err = 0;
+    /* "0" d0 d1..d6 as eight digit bytes -> the integer d0d1d2d3d4d5d6 */
+    const uint64_t d0 = x & 0xFFu;
+    uint64_t v = (x & ~0xFFFFull) | (d0 << 8);
+    v = (v * 10 + (v >> 8)) & 0x00FF00FF00FF00FFull;
+    v = (v * 100 + (v >> 16)) & 0x0000FFFF0000FFFFull;
+    const uint64_t digits = (v * 10000 + (v >> 32)) & 0xFFFFFFFFull;
+    if (__builtin_expect(d0 != 0, 1)) {
+        /* 1 <= |value| < 10: no leading zeros, one truncating division by 5^6.  The general function
+           keeps the top 24 bits of floor(digits * 2^clz / 5^6); a floor of a floor is the floor of the
+           whole quotient, so they are floor(digits * 2^t / 5^6) with t putting the result in [2^23, 2^24). */
+        const int lg = log2_digit[d0];
+        const uint32_t mant = (uint32_t)((digits << (17 - lg)) / 15625u);
+        return ((uint32_t)neg << 31) | ((uint32_t)(127 + lg) << 23) | (mant & 0x7FFFFFu);
+    }
+    if (digits == 0) return 0;
+    /* the zero scan looks at source characters [neg, 6]: d0 and the first 5 (4 after a sign) decimals.
+       A marker bit one byte past them ends the count when they are all zero (no branch on the sign). */
+    const uint64_t seen = x & (0x00FFFFFFFFFFFFFFull >> (8 * neg));
+    const int byte = __builtin_ctzll(seen | (1ull << (8 * (7 - neg)))) >> 3;
+    const int zeros = byte - 1;                           /* d0 is '0' here; the '.' byte is not a zero digit */
+    const int lead = (int)((seen >> (8 * byte)) & 0xFF);  /* 0 if every scanned digit is zero */
+    const int nd = 6 - zeros;
+    uint64_t m = digits;
+    if (nd > 0) m = xyz_div_pow5(m << __builtin_clzll(m), nd);
+    m = xyz_div_pow5(m << __builtin_clzll(m), zeros);
+    const int e2 = -zeros - __builtin_clzll(m) + log2_digit[lead];
+    const int sh = 40 - __builtin_clzll(m);
+    const uint32_t mant = (sh >= 0) ? (uint32_t)(m >> sh) : 0u;
+    return ((uint32_t)neg << 31) | ((uint32_t)((e2 + 127) & 0xFF) << 23) | (mant & 0x7FFFFFu);
+}
+
 /* one line: three tokens, each followed by exactly one separator char, then any
    run of control characters (1..31) -- reference parse.h:150-163 */
 static inline const char *xyz_parse_line(const char *s, float out[3], int *err)
@@ -101,6 +171,22 @@ static inline const char *xyz_parse_line(const char *s, float out[3], int *err)
         s = e + 1;
     }
     memcpy(out, b, 12);
+    while ((unsigned char)(*s - 1) < 31u) s++;
+    return s;
+}
+
+/* the same line when s[0..limit) is known to be readable: a line that starts far
+   enough before limit for three short-cut tokens tries the short cut on each */
+static inline const char *xyz_parse_line_bounded(const char *s, const char *limit, float out[3], int *err)
+{
+    if (limit - s < 3 * XYZ_FAST_BYTES + 2) return xyz_parse_line(s, out, err);
+    for (int a = 0; a < 3; a++) {
+        const char *e;
+        const uint32_t b = xyz_parse_float_bits_fast(s, &e, err);
+        if (*err) return e;
+        memcpy(out + a, &b, 4);
+        s = e + 1;
+    }
     while ((unsigned char)(*s - 1) < 31u) s++;
     return s;
 }

@@ -34,6 +34,39 @@ uint32_t xyz_token_bits(const char *tok, int *consumed, int *err)
     return b;
 }
 
+/* Compares the short-cut tokenizer with the general one on every token of the
+   shape it handles, "[-]d.dddddd" followed by a blank or control character
+   (2 * 10^7 tokens), and on the same digits followed by characters that must
+   send it to the general function.  Returns the number of disagreements. */
+uint64_t xyz_selfcheck_fast_tokens(void)
+{
+    static const char follow[8] = {' ', '\n', '\r', '\t', '7', 'e', 'x', 0};
+    uint64_t bad = 0;
+    char buf[24];
+    for (int neg = 0; neg < 2; neg++) {
+        for (uint32_t v = 0; v < 10000000u; v++) {
+            int k = 0;
+            if (neg) buf[k++] = '-';
+            char dg[7];
+            uint32_t d = v;
+            for (int i = 6; i >= 0; i--) { dg[i] = (char)('0' + d % 10u); d /= 10u; }
+            buf[k++] = dg[0];
+            buf[k++] = '.';
+            for (int i = 1; i < 7; i++) buf[k++] = dg[i];
+            /* mostly the four blanks; every 64th token gets one of the other followers */
+            const char f = follow[(v & 63u) == 63u ? 4 + ((v >> 6) & 3u) : (v & 3u)];
+            buf[k] = f;
+            memcpy(buf + k + 1, "-3 \n", 5);               /* something readable after it (an exponent if f is 'e') */
+            const char *e1, *e2;
+            int r1 = 0, r2 = 0;
+            const uint32_t a = xyz_parse_float_bits(buf, &e1, &r1);
+            const uint32_t b = xyz_parse_float_bits_fast(buf, &e2, &r2);
+            bad += (a != b) | (e1 != e2) | (r1 != r2);
+        }
+    }
+    return bad;
+}
+
 typedef struct {
     const char *file;
     size_t size;
@@ -57,7 +90,7 @@ static void *parse_worker(void *arg)
             j->cap = nc;
         }
         int e = 0;
-        p = xyz_parse_line(p, j->out + 3 * j->n, &e);
+        p = xyz_parse_line_bounded(p, j->file + j->size, j->out + 3 * j->n, &e);
         if (e) { j->err = e; return NULL; }
         j->n++;
     }

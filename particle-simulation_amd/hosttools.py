@@ -24,6 +24,8 @@ def lib():
         L.xyz_cell_index.argtypes = [c.c_float]
         L.xyz_token_bits.restype = c.c_uint32
         L.xyz_token_bits.argtypes = [c.c_char_p, c.POINTER(c.c_int), c.POINTER(c.c_int)]
+        L.xyz_selfcheck_fast_tokens.restype = c.c_uint64
+        L.xyz_selfcheck_fast_tokens.argtypes = []
         L.xyz_parse_buffer_mt.restype = c.c_int64
         L.xyz_parse_buffer_mt.argtypes = [c.c_char_p, c.c_uint64, c.c_int, c.c_void_p, c.c_uint64]
         L.xyz_gen_f32.restype = c.c_int64
@@ -53,6 +55,12 @@ def token_bits(tok):
     used, err = ctypes.c_int(), ctypes.c_int()
     b = lib().xyz_token_bits(tok.encode() + b"\n", ctypes.byref(used), ctypes.byref(err))
     return b, used.value, err.value
+
+
+def selfcheck_fast_tokens():
+    """Disagreements between the tokenizer's short cut and its general function over every
+    "[-]d.dddddd" token (2e7 of them) and some near misses; 0 is the only acceptable answer."""
+    return int(lib().xyz_selfcheck_fast_tokens())
 
 
 def parse_text(data, threads=4):

@@ -40,6 +40,41 @@ def test_tokenizer_matches_oracle_on_random_tokens(ht, oracle):
     assert ht.token_bits("12.5")[2] == 1 and ht.token_bits("1.5e+01")[2] == 2
 
 
+def test_tokenizer_shortcut_equals_general_on_every_token(ht):
+    """The word-at-a-time path for "[-]d.dddddd" tokens returns what the general tokenizer (pinned to the
+    reference by the vectors above) returns, on all 2e7 such tokens and on near misses."""
+    assert ht.selfcheck_fast_tokens() == 0
+
+
+def test_line_parser_on_mixed_token_shapes(ht, oracle):
+    """Lines mixing the common six-decimal shape with other digit counts, exponents, CRLF and a
+    missing final newline go through the short cut and the general path token by token."""
+    rng = np.random.default_rng(11)
+
+    def token():
+        v = int(rng.integers(0, 10 ** 7))
+        sign = "-" if rng.integers(0, 2) else ""
+        shape = int(rng.integers(0, 8))
+        if shape <= 3:
+            return "%s%d.%06d" % (sign, v // 10 ** 6, v % 10 ** 6)
+        if shape == 4:
+            return "%s%d.%03d" % (sign, v % 10, v % 1000)
+        if shape == 5:
+            return "%s%d.%09d" % (sign, v % 10, v * 97 % 10 ** 9)
+        if shape == 6:
+            return "%s%d.%06de-%d" % (sign, v % 10, v % 10 ** 6, 1 + v % 9)
+        return "%s0.%06d" % (sign, v % 1000)                 # leading zeros
+
+    for eol, last in (("\n", "\n"), ("\r\n", "\r\n"), ("\n", "")):
+        lines = [" ".join(token() for _ in range(3)) for _ in range(4000)]
+        data = (eol.join(lines) + last).encode()
+        want = oracle.parse_text(data)
+        assert want.shape == (4000, 3)
+        for threads in (1, 5):
+            got = ht.parse_text(data, threads)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (eol, last, threads)
+
+
 def test_threaded_parse_equals_sequential(ht, oracle, golden_dir):
     with open(os.path.join(golden_dir, "counts.json")) as f:
         counts = json.load(f)
