@@ -65,6 +65,12 @@ int pc_set_slab(pc_context *ctx, int x_lo, int x_hi);
    The cell key (main.c:134-136) is computed by the library on the GPU. */
 int pc_append(pc_context *ctx, const float *xyz, uint64_t n);
 
+/* Page-locked host memory for the blocks handed to pc_append: the copy is then
+   a single DMA (about half the time of a copy from pageable memory).  Allocate
+   once and reuse -- page-locking is slow.  No counterpart in the reference. */
+int pc_host_alloc(void **p, uint64_t bytes);
+int pc_host_free(void *p);
+
 /* Same, for points that already live in device memory (copied device to
    device on `stream`, which must be complete before pc_finish). */
 int pc_append_device(pc_context *ctx, const float *d_xyz, uint64_t n, void *stream);

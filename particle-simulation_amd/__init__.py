@@ -38,6 +38,8 @@ ABI = [
     ("pc_create", _i32, [_c.POINTER(_vp), _i32, _u64]),
     ("pc_set_slab", _i32, [_vp, _i32, _i32]),
     ("pc_append", _i32, [_vp, _vp, _u64]),
+    ("pc_host_alloc", _i32, [_c.POINTER(_vp), _u64]),
+    ("pc_host_free", _i32, [_vp]),
     ("pc_append_device", _i32, [_vp, _vp, _u64, _vp]),
     ("pc_finish", _i32, [_vp, _c.POINTER(_c.c_int64)]),
     ("pc_tests", _i32, [_vp, _c.POINTER(_c.c_int64)]),
@@ -111,6 +113,28 @@ def _host_ptr(arr):
     if a.ndim != 2 or a.shape[1] != 3:
         a = a.reshape(-1, 3)
     return a, a.ctypes.data_as(ctypes.c_void_p), a.shape[0]
+
+
+class HostBlock:
+    """A page-locked host buffer of `points` float triples (pc_host_alloc); `.array` is its numpy view."""
+
+    def __init__(self, points):
+        import numpy as np
+        self._p = ctypes.c_void_p()
+        _check(lib().pc_host_alloc(ctypes.byref(self._p), int(points) * 12))
+        self.array = np.ctypeslib.as_array(ctypes.cast(self._p, ctypes.POINTER(ctypes.c_float)), shape=(int(points), 3))
+
+    def close(self):
+        if self._p:
+            self.array = None
+            _check(lib().pc_host_free(self._p))
+            self._p = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 class PairCounter:

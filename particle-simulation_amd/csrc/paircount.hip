@@ -570,6 +570,24 @@ extern "C" int pc_append(pc_context *c, const float *xyz, uint64_t n)
     return PC_OK;
 }
 
+// Page-locked host memory for the blocks a producer hands to pc_append: the copy is
+// then one DMA instead of a staged copy through the runtime's own pinned buffers.
+extern "C" int pc_host_alloc(void **p, uint64_t bytes)
+{
+    if (!p) return pc_fail(PC_ERR_ARG, "pc_host_alloc: null pointer");
+    *p = NULL;
+    hipError_t e = hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return pc_fail(PC_ERR_NOMEM, "pc_host_alloc(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e));
+    return PC_OK;
+}
+
+extern "C" int pc_host_free(void *p)
+{
+    if (!p) return PC_OK;
+    PC_HIP(hipHostFree(p));
+    return PC_OK;
+}
+
 extern "C" int pc_append_device(pc_context *c, const float *d_xyz, uint64_t n, void *stream)
 {
     if (!c) return pc_fail(PC_ERR_ARG, "pc_append_device: null context");

@@ -187,6 +187,36 @@ def test_streaming_interface_threads(psa, torch_mod, oracle):
     pc.close()
 
 
+def test_append_from_page_locked_blocks(psa, torch_mod, oracle):
+    """pc_host_alloc / pc_append from several producer threads, each refilling its own
+    page-locked block (what the host program's parser threads do)."""
+    import threading
+    rng = np.random.default_rng(18)
+    xyz = rng.uniform(-1.5, 1.5, (300_000, 3)).astype(np.float32)
+    want, want_tests = oracle.count_pairs(xyz)
+    pc = psa.PairCounter(device=0, expected_points=1000)
+    errors = []
+
+    def producer(part):
+        try:
+            with psa.HostBlock(4096) as blk:
+                for first in range(0, len(part), 4096):
+                    m = min(4096, len(part) - first)
+                    blk.array[:m] = part[first:first + m]
+                    pc.append(blk.array[:m])
+        except Exception as e:                               # surfaced after join
+            errors.append(e)
+
+    th = [threading.Thread(target=producer, args=(p,)) for p in np.array_split(xyz, 5)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    assert pc.size() == len(xyz)
+    assert pc.finish() == want
+    assert pc.tests() == want_tests
+    pc.close()
+
+
 def test_full_size_properties(psa, torch_mod):
     """10 M uniform points (config 2 size): properties that need no oracle run --
     permutation invariance, shard additivity, and the tests/count relation."""
