@@ -160,8 +160,9 @@ int pc_set_variant(const char *name, int value);
    pc_profile_enable(1) also clears earlier samples.  pc_profile_read waits for
    the recorded events and writes one text line per kernel:
    "<kernel> <timed launches> <launches> <total ms of the timed launches>".
-   No counterpart in the reference (its -DTIMER phases, main.c:19-28, are the
-   closest; pc_phase_ms reports those). */
+   A measurement aid, not thread-safe: enable it only while a single host
+   thread issues stage calls.  No counterpart in the reference (its -DTIMER
+   phases, main.c:19-28, are the closest; pc_phase_ms reports those). */
 int pc_profile_enable(int on);
 int pc_profile_read(char *buf, size_t buflen);
 
