@@ -67,6 +67,46 @@ uint64_t xyz_selfcheck_fast_tokens(void)
     return bad;
 }
 
+/* Random lines over an alphabet of digits, '.', '-', 'e', blanks, control and
+   other bytes (well-formed six-decimal tokens mixed in): the bounded line
+   parser, which tries the short cut, must return the same position, error and
+   floats as the general one.  Returns the number of disagreements. */
+uint64_t xyz_selfcheck_line_fuzz(uint64_t seed, uint64_t lines)
+{
+    static const char alphabet[] = "0123456789012345678901234567890123456789....---ee  \n\r\t+x\x80\xff";
+    uint64_t bad = 0, state = seed * 2 + 1;
+    char buf[160];
+    for (uint64_t it = 0; it < lines; it++) {
+        memset(buf, 0, sizeof buf);
+        int k = 0;
+        for (int tok = 0; tok < 3; tok++) {
+            state = state * 6364136223846793005ull + 1442695040888963407ull;
+            uint64_t r = state >> 20;
+            if (r & 3) {                                  /* mostly well formed, then damaged below */
+                if (r & 4) buf[k++] = '-';
+                r >>= 3;
+                buf[k++] = (char)('0' + r % 10); r /= 10;
+                buf[k++] = '.';
+                for (int d = 0; d < 6; d++) { buf[k++] = (char)('0' + r % 10); r /= 10; }
+            } else {
+                const int len = 1 + (int)((r >> 2) % 12);
+                r >>= 6;
+                for (int d = 0; d < len; d++) { buf[k++] = alphabet[r % (sizeof alphabet - 1)]; r = r * 31 + (r >> 7) + 1; }
+            }
+            state = state * 6364136223846793005ull + 1442695040888963407ull;
+            r = state >> 24;
+            if ((r & 15) == 0) buf[(r >> 4) % (uint64_t)k] = alphabet[(r >> 12) % (sizeof alphabet - 1)];   /* damage one byte */
+            buf[k++] = tok < 2 ? ' ' : '\n';
+        }
+        float a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+        int ea = 0, eb = 0;
+        const char *pa = xyz_parse_line(buf, a, &ea);
+        const char *pb = xyz_parse_line_bounded(buf, buf + 100, b, &eb);
+        bad += (pa != pb) | (ea != eb) | (!ea && memcmp(a, b, 12) != 0);
+    }
+    return bad;
+}
+
 typedef struct {
     const char *file;
     size_t size;

@@ -26,6 +26,8 @@ def lib():
         L.xyz_token_bits.argtypes = [c.c_char_p, c.POINTER(c.c_int), c.POINTER(c.c_int)]
         L.xyz_selfcheck_fast_tokens.restype = c.c_uint64
         L.xyz_selfcheck_fast_tokens.argtypes = []
+        L.xyz_selfcheck_line_fuzz.restype = c.c_uint64
+        L.xyz_selfcheck_line_fuzz.argtypes = [c.c_uint64, c.c_uint64]
         L.xyz_parse_buffer_mt.restype = c.c_int64
         L.xyz_parse_buffer_mt.argtypes = [c.c_char_p, c.c_uint64, c.c_int, c.c_void_p, c.c_uint64]
         L.xyz_gen_f32.restype = c.c_int64
@@ -61,6 +63,11 @@ def selfcheck_fast_tokens():
     """Disagreements between the tokenizer's short cut and its general function over every
     "[-]d.dddddd" token (2e7 of them) and some near misses; 0 is the only acceptable answer."""
     return int(lib().xyz_selfcheck_fast_tokens())
+
+
+def selfcheck_line_fuzz(seed, lines):
+    """Disagreements between the bounded (short-cut) and the general line parser on random, partly damaged lines."""
+    return int(lib().xyz_selfcheck_line_fuzz(int(seed), int(lines)))
 
 
 def parse_text(data, threads=4):

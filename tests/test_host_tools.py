@@ -46,6 +46,13 @@ def test_tokenizer_shortcut_equals_general_on_every_token(ht):
     assert ht.selfcheck_fast_tokens() == 0
 
 
+def test_line_parser_fuzz_shortcut_equals_general(ht):
+    """Random and damaged lines (stray bytes, missing dots, exponents, signs in odd places): same
+    end position, error code and floats from the short-cut line parser as from the general one."""
+    for seed in (1, 2, 3):
+        assert ht.selfcheck_line_fuzz(seed, 1_000_000) == 0
+
+
 def test_line_parser_on_mixed_token_shapes(ht, oracle):
     """Lines mixing the common six-decimal shape with other digit counts, exponents, CRLF and a
     missing final newline go through the short cut and the general path token by token."""
