@@ -175,6 +175,17 @@ int pc_profile_read(char *buf, size_t buflen);
    test suite. */
 int pc_selfcheck_cell_index_device(uint64_t *d_mismatches, void *stream);
 
+/* Synthetic input on the device: points [first, first+count) of the stream
+   (kind, seed, sigma_micro) of this repository's host generator
+   (particle-simulation_amd/host/xyzhost.c: 0 = uniform, 1 = 64 Gaussian
+   blobs, 2 = a ramp through every six-decimal value), bit for bit what the host
+   generator writes -- i.e. what the reference tokenizer (parse.h:24-163)
+   returns for the stream's text -- as packed float triples in d_xyz.  For
+   benchmarks whose input would otherwise be generated on the host and copied.
+   No counterpart in the reference (it has no generator). */
+int pc_generate_device(int kind, uint64_t seed, int64_t sigma_micro, uint64_t first, uint64_t count,
+                       float *d_xyz, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

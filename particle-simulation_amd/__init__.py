@@ -56,6 +56,7 @@ ABI = [
     ("pc_profile_enable", _i32, [_i32]),
     ("pc_profile_read", _i32, [_c.c_char_p, _sz]),
     ("pc_selfcheck_cell_index_device", _i32, [_vp, _vp]),
+    ("pc_generate_device", _i32, [_i32, _u64, _c.c_int64, _u64, _u64, _vp, _vp]),
 ]
 
 
@@ -275,6 +276,21 @@ class DeviceStages:
 
     def tests(self):
         return int(self.result[1].item())
+
+
+def generate_device(kind, seed, count, sigma_micro=0, first=0, device="cuda:0", x_lo=0, x_hi=PC_NLAYERS - 1):
+    """Points [first, first+count) of the host generator's stream (hosttools.generate), made on the GPU
+    bit for bit; with x_lo/x_hi only those whose x cell lies in [x_lo, x_hi], in stream order."""
+    import torch
+    dev = torch.device(device)
+    out = torch.empty((int(count), 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib().pc_generate_device(int(kind), int(seed), int(sigma_micro), int(first), int(count), out.data_ptr(),
+                                        torch.cuda.current_stream(dev).cuda_stream))
+    if x_lo > 0 or x_hi < PC_NLAYERS - 1:
+        cx = ((out[:, 0].double() + 10.0) / 0.05).to(torch.int32)      # the reference's cell formula (main.c:134)
+        out = out[(cx >= x_lo) & (cx <= x_hi)].contiguous()
+    return out
 
 
 def count_pairs(xyz, device="cuda:0", x_lo=0, x_hi=PC_NLAYERS):

@@ -15,6 +15,7 @@
 #include "pc_count_tile.h"
 #include "pc_count_wave.h"
 #include "pc_count_group.h"
+#include "pc_generate.h"
 
 // ------------------------------------------------------------------ errors --
 static thread_local char g_err[512] = "";
@@ -259,6 +260,19 @@ static inline int grid_for(uint64_t n, int tpb, int cap)
     if (g < 1) g = 1;
     if (g > (uint64_t)cap) g = cap;
     return (int)g;
+}
+
+extern "C" int pc_generate_device(int kind, uint64_t seed, int64_t sigma_micro, uint64_t first, uint64_t count,
+                                  float *d_xyz, void *stream)
+{
+    if (kind < PC_GEN_UNIFORM || kind > PC_GEN_RAMP) return pc_fail(PC_ERR_ARG, "pc_generate_device: kind %d unknown", kind);
+    if (count == 0) return PC_OK;
+    if (!d_xyz) return pc_fail(PC_ERR_ARG, "pc_generate_device: null output");
+    if (count > PC_MAX_POINTS) return pc_fail(PC_ERR_ARG, "pc_generate_device: count too large");
+    PC_LAUNCH("pc_gen_points", pc_gen_points, dim3(grid_for(count, 256, 16384)), dim3(256), (hipStream_t)stream,
+              kind, seed, sigma_micro, first, count, d_xyz);
+    PC_HIP(hipGetLastError());
+    return PC_OK;
 }
 
 extern "C" int pc_selfcheck_cell_index_device(uint64_t *d_mismatches, void *stream)

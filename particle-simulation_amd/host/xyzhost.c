@@ -175,6 +175,7 @@ int64_t xyz_parse_buffer_mt(const char *buf, uint64_t len, int nthreads, float *
 /* ---- generator -------------------------------------------------------------- */
 #define XYZ_KIND_UNIFORM 0
 #define XYZ_KIND_BLOBS 1
+#define XYZ_KIND_RAMP 2           /* every micro-unit value in turn (checks of the conversion, not a workload) */
 #define XYZ_SPAN 9999000          /* coordinates in [-9.999000, 9.999000] */
 #define XYZ_NBLOBS 64
 
@@ -197,6 +198,11 @@ void xyz_point_micro(int kind, uint64_t seed, uint64_t i, int64_t sigma_micro, i
     if (kind == XYZ_KIND_UNIFORM) {
         for (unsigned a = 0; a < 3; a++)
             m[a] = (int64_t)(xyz_draw(seed, i, a) % (2u * XYZ_SPAN + 1u)) - XYZ_SPAN;
+        return;
+    }
+    if (kind == XYZ_KIND_RAMP) {
+        for (unsigned a = 0; a < 3; a++)
+            m[a] = (int64_t)((i * 3u + a) % (2u * XYZ_SPAN + 1u)) - XYZ_SPAN;
         return;
     }
     /* Gaussian blobs: 64 centres uniform in (-8,8)^3; each offset is a sum of 12

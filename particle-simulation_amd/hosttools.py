@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libxyzhost.so")
 MAIN_PATH = os.path.join(HERE, "main")
 
-UNIFORM, BLOBS = 0, 1
+UNIFORM, BLOBS, RAMP = 0, 1, 2
 _lib = None
 
 

@@ -217,6 +217,24 @@ def test_append_from_page_locked_blocks(psa, torch_mod, oracle):
     pc.close()
 
 
+def test_device_generator_equals_host_generator(psa, torch_mod):
+    """pc_generate_device against the host generator, bit for bit: the ramp stream walks every
+    six-decimal value of the domain (all 19 998 001 of them, both signs, leading-zero quirks
+    included), then the two workload streams at an offset, then a slab selection."""
+    import importlib
+    torch = torch_mod
+    ht = importlib.import_module("particle_simulation_amd.hosttools")
+    n_ramp = (2 * 9_999_000 + 1 + 2) // 3 + 5
+    for kind, n, sigma, first in ((ht.RAMP, n_ramp, 0, 0), (ht.UNIFORM, 2_000_000, 0, 12_345),
+                                  (ht.BLOBS, 2_000_000, 120_000, 777), (ht.BLOBS, 500_000, 500_000, 0)):
+        want = ht.generate(kind, 42, n, sigma, first=first)
+        got = psa.generate_device(kind, 42, n, sigma, first=first).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (kind, n, sigma)
+    want = ht.generate(ht.UNIFORM, 9, 1_000_000, 0, x_lo=100, x_hi=150)
+    got = psa.generate_device(ht.UNIFORM, 9, 1_000_000, 0, x_lo=100, x_hi=150).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_full_size_properties(psa, torch_mod):
     """10 M uniform points (config 2 size): properties that need no oracle run --
     permutation invariance, shard additivity, and the tests/count relation."""
