@@ -278,19 +278,32 @@ class DeviceStages:
         return int(self.result[1].item())
 
 
-def generate_device(kind, seed, count, sigma_micro=0, first=0, device="cuda:0", x_lo=0, x_hi=PC_NLAYERS - 1):
+def generate_device(kind, seed, count, sigma_micro=0, first=0, device="cuda:0", x_lo=0, x_hi=PC_NLAYERS - 1,
+                    piece=50_000_000):
     """Points [first, first+count) of the host generator's stream (hosttools.generate), made on the GPU
-    bit for bit; with x_lo/x_hi only those whose x cell lies in [x_lo, x_hi], in stream order."""
+    bit for bit; with x_lo/x_hi only those whose x cell lies in [x_lo, x_hi], in stream order.
+    A selection is made piece by piece, so only the kept points and one piece are ever resident."""
     import torch
     dev = torch.device(device)
-    out = torch.empty((int(count), 3), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        _check(lib().pc_generate_device(int(kind), int(seed), int(sigma_micro), int(first), int(count), out.data_ptr(),
-                                        torch.cuda.current_stream(dev).cuda_stream))
-    if x_lo > 0 or x_hi < PC_NLAYERS - 1:
-        cx = ((out[:, 0].double() + 10.0) / 0.05).to(torch.int32)      # the reference's cell formula (main.c:134)
-        out = out[(cx >= x_lo) & (cx <= x_hi)].contiguous()
-    return out
+    count, first = int(count), int(first)
+    select = x_lo > 0 or x_hi < PC_NLAYERS - 1
+
+    def make(start, m):
+        out = torch.empty((m, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _check(lib().pc_generate_device(int(kind), int(seed), int(sigma_micro), start, m, out.data_ptr(),
+                                            torch.cuda.current_stream(dev).cuda_stream))
+        return out
+
+    if not select:
+        return make(first, count)
+    kept = []
+    for start in range(first, first + count, piece):
+        part = make(start, min(piece, first + count - start))
+        cx = ((part[:, 0].double() + 10.0) / 0.05).to(torch.int32)      # the reference's cell formula (main.c:134)
+        kept.append(part[(cx >= x_lo) & (cx <= x_hi)])
+        del part, cx
+    return torch.cat(kept).contiguous() if kept else torch.empty((0, 3), dtype=torch.float32, device=dev)
 
 
 def count_pairs(xyz, device="cuda:0", x_lo=0, x_hi=PC_NLAYERS):
