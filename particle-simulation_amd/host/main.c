@@ -11,6 +11,9 @@
  * GPU library (pc_append from a page-locked block), and where main() calls flatten()+count()
  * (main.c:331-335) this calls pc_finish().  -c is accepted for compatibility:
  * the counting threads it sized are replaced by GPU kernels.
+ * A data file whose name ends in ".f32" is taken as the parsed form of such a
+ * file -- packed binary32 x,y,z triples -- and appended without tokenizing
+ * (kernel-side runs at sizes where the text would be tens of gigabytes).
  * With PAIRCOUNT_TIMER=1 in the environment the four phase times the
  * reference's -DTIMER build prints are written to stderr.
  */
@@ -38,6 +41,7 @@ typedef struct {
     int status;              /* 0 ok, 1 tokenizer error, 2 library error */
     double append_us;        /* time this thread spent inside pc_append */
     float *block;            /* this thread's page-locked block of BLOCK_POINTS points */
+    int binary;              /* the file holds float triples, not text */
     char msg[256];
 } worker;
 
@@ -57,9 +61,22 @@ static int append_block(worker *w, const float *block, uint64_t n)
     return rc;
 }
 
+/* ".f32" input: thread t appends its share of the triples straight from the mapping */
+static void append_binary_share(worker *w)
+{
+    const uint64_t total = w->size / 12;
+    const uint64_t first = total * (uint64_t)w->t / (uint64_t)w->nt, last = total * (uint64_t)(w->t + 1) / (uint64_t)w->nt;
+    const float *pts = (const float *)w->file;
+    for (uint64_t i = first; i < last; i += 16 * BLOCK_POINTS) {
+        const uint64_t m = last - i < 16 * BLOCK_POINTS ? last - i : 16 * BLOCK_POINTS;
+        if (append_block(w, pts + 3 * i, m) != PC_OK) return;
+    }
+}
+
 static void *parser_thread(void *arg)
 {
     worker *w = (worker *)arg;
+    if (w->binary) { append_binary_share(w); return NULL; }
     float *block = w->block;
     const char *p, *stop;
     xyz_thread_range(w->file, w->size, w->t, w->nt, &p, &stop);
@@ -129,8 +146,14 @@ int main(int argc, char **argv)
     /* The tokenizer looks one character past the last line (as the reference
        does).  The zero fill of the last mapped page provides it, except when the
        size is an exact page multiple: then read the file into a terminated buffer. */
+    const size_t name_len = strlen(file_name);
+    const int binary = name_len > 4 && strcmp(file_name + name_len - 4, ".f32") == 0;
+    if (binary && size % 12 != 0) {
+        fprintf(stderr, "%s: %zu bytes is not a whole number of float triples\n", file_name, size);
+        return -1;
+    }
     const size_t page = (size_t)sysconf(_SC_PAGESIZE);
-    const int mapped = size && (size % page) != 0;
+    const int mapped = size && (binary || (size % page) != 0);
     char *file = NULL;
     if (mapped) {
         file = mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
@@ -149,7 +172,7 @@ int main(int argc, char **argv)
 
     int device = getenv("PAIRCOUNT_DEVICE") ? atoi(getenv("PAIRCOUNT_DEVICE")) : 0;
     pc_context *ctx = NULL;
-    if (pc_create(&ctx, device, size / 24 + 1024) != PC_OK) {
+    if (pc_create(&ctx, device, binary ? size / 12 + 1 : size / 24 + 1024) != PC_OK) {
         fprintf(stderr, "pc_create: %s\n", pc_last_error());
         return -1;
     }
@@ -167,7 +190,7 @@ int main(int argc, char **argv)
     }
     for (int t = 0; t < pthreads; t++) {
         w[t] = (worker){.file = file, .size = size, .t = t, .nt = pthreads, .ctx = ctx, .status = 0,
-                        .block = pinned + (size_t)t * BLOCK_POINTS * 3};
+                        .block = pinned + (size_t)t * BLOCK_POINTS * 3, .binary = binary};
         if (size == 0) continue;
         if (pthread_create(&th[t], NULL, parser_thread, &w[t]) != 0) { perror("pthread_create"); exit(-1); }
     }

@@ -47,6 +47,24 @@ def test_main_on_generated_file_with_timer(ht, oracle, tmp_path):
     assert int(r.stdout) == oracle.count_pairs(xyz)[0] and n == 300_000
 
 
+def test_main_on_binary_sidecar(ht, golden_dir, tmp_path):
+    """A ".f32" file (the parsed bits of a .xyz file) gives the count of the text file it came from."""
+    with open(os.path.join(golden_dir, "counts.json")) as f:
+        counts = json.load(f)
+    for name, info in counts.items():
+        pts = np.load(os.path.join(golden_dir, name.replace(".xyz", ".f32.npy")))
+        path = str(tmp_path / name.replace(".xyz", ".f32"))
+        pts.astype(np.float32).tofile(path)
+        for p in ("1", "5"):
+            r = subprocess.run([ht.MAIN_PATH, "-f", path, "-p", p], capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, (name, r.stderr)
+            assert r.stdout == "%d\n" % info["count"], (name, p, r.stdout)
+    empty = tmp_path / "empty.f32"
+    empty.write_bytes(b"")
+    r = subprocess.run([ht.MAIN_PATH, "-f", str(empty)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout == "0\n"
+
+
 def test_main_reports_tokenizer_errors_like_the_reference(ht, tmp_path):
     bad = tmp_path / "bad.xyz"
     bad.write_text("1.000000 2.000000 3.000000\n12.500000 1.000000 1.000000\n" * 8)

@@ -128,7 +128,7 @@ def test_slab_router_and_cuts(ht, oracle):
         assert np.array_equal(direct.view(np.uint32), want.view(np.uint32))
 
 
-def test_cli_surface(ht):
+def test_cli_surface(ht, tmp_path):
     main = ht.MAIN_PATH
     assert os.path.exists(main)
     r = subprocess.run([main, "-h"], capture_output=True, text=True)
@@ -139,3 +139,7 @@ def test_cli_surface(ht):
     assert r.returncode == 255 and "open" in r.stderr
     r = subprocess.run([main, "-f", "x", "-p", "0"], capture_output=True, text=True)
     assert r.returncode == 255
+    ragged = tmp_path / "ragged.f32"
+    ragged.write_bytes(b"\0" * 25)                       # binary input must be whole float triples
+    r = subprocess.run([main, "-f", str(ragged)], capture_output=True, text=True)
+    assert r.returncode == 255 and "whole number of float triples" in r.stderr
