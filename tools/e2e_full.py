@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--workload", default="uniform100m")
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--skip-reference", action="store_true", help="time only the product's host program")
+    ap.add_argument("--sidecar", action="store_true",
+                    help="also time the host program on the .f32 form of the same points (no tokenizing)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "e2e_full.json"))
     args = ap.parse_args()
     from __graft_entry__ import load_package
@@ -63,6 +65,16 @@ def main():
             out["reference"] = {"wall_s": w, "count": int([ln for ln in r.stdout.splitlines() if ln.strip().isdigit()][-1]),
                                 "phases_s": {m.group(1): int(m.group(2)) / 1e6 for m in re.finditer(r"(\w+):\s+(\d+) us", r.stdout)}}
             out["counts_equal"] = out["reference"]["count"] == out["gpu_host_program"]["count"]
+        if args.sidecar:
+            side = os.path.join(tmp, "input.f32")
+            ht.generate(kind, 7, points, sigma).tofile(side)
+            try:
+                w, r = timed([ht.MAIN_PATH, "-f", side, "-p", str(args.threads)], env=dict(os.environ, PAIRCOUNT_TIMER="1"))
+                out["gpu_host_program_f32_sidecar"] = {
+                    "wall_s": w, "count": int(r.stdout.strip()), "file_bytes": os.path.getsize(side),
+                    "phases_s": {m.group(1): float(m.group(2)) / 1e6 for m in re.finditer(r"(\w[\w()]*):\s+(\d+) us", r.stderr)}}
+            finally:
+                os.remove(side)
     finally:
         os.remove(path)
         os.rmdir(tmp)
