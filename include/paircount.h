@@ -151,7 +151,9 @@ int pc_count_pairs_device(const float *d_xyz, uint64_t n, int x_lo, int x_hi,
 /* Selects kernel variants (for A/B measurement and cross-checks); values are
    documented next to the kernels.  name: "bin" | "count", or "segments": the
    capacity of the pair test's list of heavy-pencil segments (default and
-   maximum 262144; 0 = never cut a pencil).  Returns PC_ERR_ARG for an unknown
+   maximum 262144; 0 = never cut a pencil), or "heavy": the capacity of its list
+   of over-full cells' home-particle chunks (default and maximum 65536; 0 = such
+   cells are processed by the wave that meets them).  Returns PC_ERR_ARG for an unknown
    name or value. */
 int pc_set_variant(const char *name, int value);
 

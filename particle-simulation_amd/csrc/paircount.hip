@@ -45,6 +45,7 @@ static int g_variant_bin = 1;     // 0 = atomic counting sort, 1 = LDS-staged th
 // 0 = global memory, 1 = LDS-tiled strips, 2 = wave per pencil, 3 = candidate-parallel groups,
 // 4 = by density: 0 below 0.8 points per cell of the slab on average, else 3
 static int g_variant_count = 4;
+static int g_heavy = PC_G_HEAVY_CAP;      // capacity of the list of over-full cells' home-particle chunks (0: never listed)
 static int g_segments = PC_G_SEG_CAP;   // capacity of the heavy-pencil segment list (0: pencils are never cut)
 
 extern "C" int pc_set_variant(const char *name, int value)
@@ -58,6 +59,11 @@ extern "C" int pc_set_variant(const char *name, int value)
     if (!strcmp(name, "count")) {
         if (value < 0 || value > 4) return pc_fail(PC_ERR_ARG, "pc_set_variant: count variant %d unknown", value);
         g_variant_count = value;
+        return PC_OK;
+    }
+    if (!strcmp(name, "heavy")) {
+        if (value < 0 || value > PC_G_HEAVY_CAP) return pc_fail(PC_ERR_ARG, "pc_set_variant: heavy-cell list capacity %d not in [0,%d]", value, PC_G_HEAVY_CAP);
+        g_heavy = value;
         return PC_OK;
     }
     if (!strcmp(name, "segments")) {
@@ -344,7 +350,7 @@ static int bin_layers(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
 }
 
 // Work area of the persistent pair-test kernel (layout: pc_count_group.h): work
-// counters, the per-pencil "planned" flags and the segment list, 2.2 MB in the
+// counters, the per-pencil "planned" flags and the segment list and the list of over-full cells, 2.8 MB in the
 // code object (each device holds its own copy).  The counters are zeroed on the
 // launch stream before every launch, flags and segments are rewritten by the
 // planning kernel.  Two pair-test launches that overlap on one device would
@@ -427,7 +433,12 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
         const int want = resident, most = ((x_hi - x_lo) * PC_NLAYERS + PC_G_WAVES - 1) / PC_G_WAVES;
         const int grid = ((want < most ? want : most) + 7) / 8 * 8;
         PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
-                  d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, (uint32_t)g_segments, (unsigned long long *)d_npairs);
+                  d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, (uint32_t)g_segments, (uint32_t)g_heavy,
+                  (unsigned long long *)d_npairs);
+        // the home particles of over-full cells that the waves listed instead of processing (normally none:
+        // the workgroups then return at once)
+        PC_LAUNCH("pc_c3_heavy", pc_c3_heavy, dim3(resident >= 2048 ? 2048 : resident), dim3(PC_G_HEAVY_CHUNK), (hipStream_t)stream,
+                  d_sorted_xyz, d_cell_start, queue, (uint32_t)g_heavy, (unsigned long long *)d_npairs);
     } else if (variant == 2) {
         const int grid = 8 * (x_hi - x_lo) * PC_W_WG_PER_BAND;
         PC_LAUNCH("pc_c2_count_waves", pc_c2_count_waves, dim3(grid), dim3(PC_W_WAVES * 64), (hipStream_t)stream,

@@ -47,7 +47,20 @@
 #define PC_G_FLAG_WORDS ((PC_NBB * PC_NBB + 3) / 4 + 3)
 #define PC_G_SEGS (PC_G_FLAGS + PC_G_FLAG_WORDS)
 #define PC_G_SEG_CAP 262144
-#define PC_G_WORK_WORDS (PC_G_SEGS + 2 * PC_G_SEG_CAP)
+// A single cell so full that its pairs are too much for one wave (many points in one
+// place) is not processed by the wave that meets it: its home particles go, 256 at a
+// time, on a list that a follow-up kernel (pc_c3_heavy, thread per home particle)
+// works through with the whole GPU.
+//   [PC_G_HEAVY_COUNT]               items appended
+//   [PC_G_HEAVY, +2*PC_G_HEAVY_CAP)  items: cell key (0xFFFFFFFF = void), chunk of 256 home particles
+#define PC_G_HEAVY_COUNT 304
+#define PC_G_HEAVY (PC_G_SEGS + 2 * PC_G_SEG_CAP)
+#define PC_G_HEAVY_CAP 65536
+#define PC_G_HEAVY_CHUNK 256
+#ifndef PC_G_HEAVY_COST
+#define PC_G_HEAVY_COST (1ull << 20)     // home particles x candidates of one cell from which on it is listed
+#endif
+#define PC_G_WORK_WORDS (PC_G_HEAVY + 2 * PC_G_HEAVY_CAP)
 #ifndef PC_G_PLAN_MIN_POINTS
 #define PC_G_PLAN_MIN_POINTS 2048        // pencils with fewer points are never cut
 #endif
@@ -354,7 +367,8 @@ pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__r
 
 __global__ void __launch_bounds__(PC_G_WAVES * 64, 4)   // registers and LDS admit 5 waves per SIMD
 pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T, int x_lo, int x_hi,
-                   unsigned int *__restrict__ queue, uint32_t seg_cap, unsigned long long *__restrict__ out)
+                   unsigned int *__restrict__ queue, uint32_t seg_cap, uint32_t heavy_cap,
+                   unsigned long long *__restrict__ out)
 {
     __shared__ pc_group_lds lds_all[PC_G_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -586,7 +600,7 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                 // ---- home cell z0 with its neighbours does not fit: stream the
                 //      candidate ranges through LDS in pieces ---------------------
                 const uint32_t h0 = pc_lane_value(s[0], th0);
-                const uint32_t h1 = h0 + pc_lane_value(n[0], th0);
+                uint32_t h1 = h0 + pc_lane_value(n[0], th0);
                 uint32_t c_lo[5], c_hi[5];
 #pragma unroll
                 for (int r = 0; r < 5; r++) {
@@ -594,6 +608,26 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                     c_lo[r] = r == 0 ? h0 : pc_lane_value(s[r], 0);
                     const int te = min(th0 + 1, 63);
                     c_hi[r] = pc_lane_value(s[r], te) + pc_lane_value(n[r], te);
+                }
+                // too much for one wave: list the cell's home particles for pc_c3_heavy instead
+                {
+                    const uint32_t nhome = h1 - h0;
+                    const uint32_t ncand = (c_hi[0] - c_lo[0]) + (c_hi[1] - c_lo[1]) + (c_hi[2] - c_lo[2]) +
+                                           (c_hi[3] - c_lo[3]) + (c_hi[4] - c_lo[4]);
+                    if ((unsigned long long)nhome * ncand >= PC_G_HEAVY_COST) {
+                        const uint32_t chunks = (nhome + PC_G_HEAVY_CHUNK - 1) / PC_G_HEAVY_CHUNK;
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(queue + PC_G_HEAVY_COUNT, chunks);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        const bool room = base + chunks <= heavy_cap && base + chunks >= base;
+                        const uint32_t key = tb[0] + (uint32_t)z0;
+                        // (an append that does not fit voids the slots it drew; the cell is then processed here)
+                        for (uint32_t c = lane; c < chunks && base + c < heavy_cap; c += 64) {
+                            queue[PC_G_HEAVY + 2 * (base + c)] = room ? key : 0xFFFFFFFFu;
+                            queue[PC_G_HEAVY + 2 * (base + c) + 1] = c;
+                        }
+                        if (room) h1 = h0;                  // nothing left to do for this cell here
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 5; r++) {
@@ -631,11 +665,56 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                         }
                     }
                 }
-                done = h1;
+                done = h0 + pc_lane_value(n[0], th0);
             }
             z0 = z_next;
         }
         m = __builtin_amdgcn_readfirstlane(m_next);
     }
     pc_block_add_u64<PC_G_WAVES>(acc, out);
+}
+
+// The listed home particles of over-full cells: one thread per home particle, its
+// candidates (the cell's later slots and the cell above, then the three-cell runs of
+// the four neighbour pencils: main.c:195-221) read through the caches -- every
+// thread of a workgroup walks the same ranges, so the reads are broadcasts.
+__global__ void __launch_bounds__(PC_G_HEAVY_CHUNK)
+pc_c3_heavy(const float *__restrict__ pts, const uint32_t *__restrict__ T, const unsigned int *__restrict__ work,
+            uint32_t heavy_cap, unsigned long long *__restrict__ out)
+{
+    const uint32_t items = min(work[PC_G_HEAVY_COUNT], heavy_cap);
+    if (items == 0) return;
+    struct pt3 { float x, y, z; };
+    const pt3 *P = reinterpret_cast<const pt3 *>(pts);
+    unsigned long long acc = 0;
+    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const uint32_t key = work[PC_G_HEAVY + 2 * item], chunk = work[PC_G_HEAVY + 2 * item + 1];
+        if (key == 0xFFFFFFFFu) continue;
+        const uint32_t p = T[key] + chunk * PC_G_HEAVY_CHUNK + threadIdx.x;
+        if (p >= T[key + 1]) continue;
+        const pt3 me = P[p];
+        const uint32_t base[5] = {0u, 402u, 162005u, 162408u, 162811u};
+        uint32_t lo[5], hi[5];
+        lo[0] = p + 1;
+        hi[0] = T[key + 2];
+#pragma unroll
+        for (int r = 1; r < 5; r++) {
+            lo[r] = T[key + base[r]];
+            hi[r] = T[key + base[r] + 3];
+        }
+        const pc_v2f ax = {me.x, me.x}, ay = {me.y, me.y}, az = {me.z, me.z};
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            for (uint32_t q = lo[r]; q < hi[r]; q += 2) {
+                const pt3 v0 = P[q], v1 = P[min(q + 1, hi[r] - 1)];
+                const pc_v2f cx = {v0.x, v1.x}, cy = {v0.y, v1.y}, cz = {v0.z, v1.z};
+                const pc_v2f dx = ax - cx, dy = ay - cy, dz = az - cz;
+                const pc_v2f sq = (dx * dx + dy * dy) + dz * dz;         // unfused: see the build flags
+                cnt += (sq.x <= 0.0025f) + ((sq.y <= 0.0025f) & (q + 1 < hi[r]));
+            }
+        }
+        acc += cnt;
+    }
+    pc_block_add_u64<PC_G_HEAVY_CHUNK / 64>(acc, out);
 }

@@ -315,7 +315,7 @@ def _cell_box(rng, n, lo_cell, hi_cell):
     return rng.uniform(lo, hi, (n, 3))
 
 
-@pytest.mark.parametrize("shape", ["pencil", "two_pencils", "sheet", "gradient", "needle_in_dust", "layer_pair"])
+@pytest.mark.parametrize("shape", ["pencil", "two_pencils", "sheet", "gradient", "needle_in_dust", "layer_pair", "heavy_block"])
 def test_density_regimes(psa, stages, torch_mod, oracle, shape):
     """Inputs that drive the pair test through every window regime (sparse groups,
     wide groups, dense windows, piece-wise streaming) and through the switches
@@ -334,6 +334,10 @@ def test_density_regimes(psa, stages, torch_mod, oracle, shape):
     elif shape == "needle_in_dust":        # one cell with 5000 points inside sparse background
         xyz = np.concatenate([rng.uniform(-9.999, 9.999, (150_000, 3)),
                               _cell_box(rng, 5000, (57, 311, 123), (58, 312, 124))])
+    elif shape == "heavy_block":           # an over-full cell (listed for the thread-per-particle kernel) amid full neighbours
+        xyz = np.concatenate([_cell_box(rng, 12_000, (120, 77, 301), (121, 78, 302)),
+                              _cell_box(rng, 27 * 300, (119, 76, 300), (122, 79, 303)),
+                              _cell_box(rng, 9_000, (120, 77, 302), (121, 78, 303))])    # and a second one right above it
     else:                                  # two adjacent x layers, moderately dense: all five rows populated
         xyz = _cell_box(rng, 400_000, (250, 150, 150), (252, 250, 250))
     xyz = xyz.astype(np.float32)
@@ -342,6 +346,24 @@ def test_density_regimes(psa, stages, torch_mod, oracle, shape):
         got, tests, _ = gpu_count(psa, stages, torch_mod, xyz, bin_v=bv, count_v=cv)
         assert got == want, (shape, bv, cv)
         assert tests == want_tests
+
+
+def test_heavy_cell_list_overflow(psa, stages, torch_mod, oracle):
+    """Over-full cells are handed to a follow-up kernel through a list; when the list is too
+    short (capacity 0, 1, a few) the wave that met the cell processes it itself: same count."""
+    rng = np.random.default_rng(77)
+    xyz = np.concatenate([_cell_box(rng, 3_000, (5, 5, 5), (6, 6, 6)),           # 12 chunks of 256
+                          _cell_box(rng, 2_500, (5, 5, 6), (6, 6, 7)),           # 10 chunks, the cell above
+                          _cell_box(rng, 2_000, (300, 399, 399), (301, 400, 400)),
+                          rng.uniform(-9.999, 9.999, (50_000, 3))]).astype(np.float32)
+    want, want_tests = oracle.count_pairs(xyz)
+    try:
+        for cap in (65536, 0, 1, 9, 12, 21, 22, 30):
+            psa.set_variant("heavy", cap)
+            got, tests, _ = gpu_count(psa, stages, torch_mod, xyz, bin_v=1, count_v=3)
+            assert got == want and tests == want_tests, cap
+    finally:
+        psa.set_variant("heavy", 65536)
 
 
 def test_two_contexts_finish_concurrently(psa, torch_mod, oracle):
