@@ -12,9 +12,13 @@
 //   (int)((f - (-10.)) / 0.05)   with f promoted to double.
 // f - (-10.0) and f + 10.0 are the same IEEE operation; the divide must stay a
 // correctly rounded binary64 division (no reciprocal multiply).
+// A NaN or a quotient beyond int converts to INT_MIN, as cvttsd2si does in the
+// reference's build (the GPU conversion would give 0 for NaN: a valid cell).
 __device__ __forceinline__ int pc_cell_index_exact(float f)
 {
-    return (int)(((double)f + 10.0) / 0.05);
+    const double q = ((double)f + 10.0) / 0.05;
+    if (!(q > -2147483649.0 && q < 2147483648.0)) return (int)0x80000000;
+    return (int)q;
 }
 
 // The same value at binary32 cost for all but about 2 points in 1000.

@@ -147,6 +147,14 @@ def test_edge_cases(psa, stages, torch_mod, oracle):
     # out-of-domain input is an error, not a wrong answer
     with pytest.raises(psa.PairCountError):
         gpu_count(psa, stages, torch_mod, np.array([[10.5, 0.0, 0.0], [0, 0, 0]], np.float32))
+    # ... and so are NaN and infinities on any axis, in both binning variants
+    for bad in (np.nan, np.inf, -np.inf, 3.0e38):
+        for axis in range(3):
+            pts = np.zeros((3, 3), np.float32)
+            pts[1, axis] = bad
+            for bv in (0, 1):
+                with pytest.raises(psa.PairCountError):
+                    gpu_count(psa, stages, torch_mod, pts, bin_v=bv, count_v=4)
 
 
 def test_slab_shards_sum_to_whole(psa, stages, torch_mod, oracle):
