@@ -478,10 +478,19 @@ pc_l7b_sort_big_pencils(const float *__restrict__ src, float *__restrict__ dst,
             float *od = dst + 3 * (uint64_t)base;
             for (uint32_t d = tid; d < nd; d += PC_L7B_TPB) od[d] = stage[d];
         } else {
-            for (uint32_t i = tid; i < n; i += PC_L7B_TPB) {
-                const int k = pc_cell_index(g[i].z);
-                if ((unsigned)k < 400u) atomicAdd(&hist[k], 1u);
-                else bad = true;
+            // (four points per thread and turn: four loads in flight -- a single workgroup is latency bound)
+            for (uint32_t i0 = tid; i0 < n; i0 += 4 * PC_L7B_TPB) {
+                float zz[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) zz[u] = g[min(i0 + u * PC_L7B_TPB, n - 1)].z;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (i0 + u * PC_L7B_TPB < n) {
+                        const int k = pc_cell_index(zz[u]);
+                        if ((unsigned)k < 400u) atomicAdd(&hist[k], 1u);
+                        else bad = true;
+                    }
+                }
             }
             __syncthreads();
             if (tid < 64) pc_l7_scan_bins(hist, tid);
@@ -489,10 +498,17 @@ pc_l7b_sort_big_pencils(const float *__restrict__ src, float *__restrict__ dst,
             for (int k = tid; k < PC_NBB; k += PC_L7B_TPB) slice[k] = base + hist[k];
             __syncthreads();
             pc_pt3 *o = reinterpret_cast<pc_pt3 *>(dst) + base;
-            for (uint32_t i = tid; i < n; i += PC_L7B_TPB) {
-                const pc_pt3 v = g[i];
-                const int k = pc_cell_index(v.z);
-                if ((unsigned)k < 400u) o[atomicAdd(&hist[k], 1u)] = v;
+            for (uint32_t i0 = tid; i0 < n; i0 += 4 * PC_L7B_TPB) {
+                pc_pt3 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = g[min(i0 + u * PC_L7B_TPB, n - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (i0 + u * PC_L7B_TPB < n) {
+                        const int k = pc_cell_index(v[u].z);
+                        if ((unsigned)k < 400u) o[atomicAdd(&hist[k], 1u)] = v[u];
+                    }
+                }
             }
         }
     }
