@@ -12,6 +12,12 @@ each rank holds its slab's points plus the +x halo layer.
 
 Prints ONE JSON line on rank 0.  value = reference dist2() evaluations covered
 per second by the whole job (tests of all ranks / max-over-ranks step time).
+
+`python bench.py --gpus N` with N > 1 and no rank environment starts the N ranks
+itself: the parent touches no GPU, starts N fresh child processes of this file
+with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, relays rank
+0's line and exits with the worst child status.  Under torch.distributed.run the
+ranks already exist and nothing is spawned.
 """
 import argparse
 import json
@@ -59,6 +65,29 @@ def kernel_bytes(name, n, layers):
     return table.get(name)
 
 
+def spawn_ranks(n):
+    """The parent of a self-launched multi-rank run: no torch, no HIP, only child processes."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    worst = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        if p.returncode != 0 and worst == 0:
+            worst = p.returncode
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    sys.exit(worst if worst >= 0 else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,7 +108,12 @@ def main():
     ap.add_argument("--as-rank", type=int, nargs=2, metavar=("R", "W"), default=None,
                     help="single process, no collective: time the slab that rank R of a W-rank run would hold "
                          "(a per-rank preview of the N-GPU line on a one-GPU box; not a bench result)")
+    ap.add_argument("--no-e2e-full", action="store_true",
+                    help="skip the full-size end-to-end leg of cpu_baseline (reference program and the product's host "
+                         "program on the whole workload written as a text file)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.as_rank:
+        spawn_ranks(args.gpus)
 
     import numpy as np
     import torch
@@ -92,10 +126,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-        args.gpus = world
+    args.gpus = world
+    if args.backend == "nccl" and world > torch.cuda.device_count():
+        sys.exit("bench.py: %d ranks but %d GPUs; --backend gloo rehearses more ranks than GPUs" % (world, torch.cuda.device_count()))
     dev_index = local_rank % torch.cuda.device_count() if args.backend == "gloo" else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -180,15 +213,28 @@ def main():
     pairs_local = st.pairs()
     st.count_tests(x_lo, x_hi)
     tests_local = st.tests()
-    agg = torch.tensor([pairs_local, tests_local, n], dtype=torch.int64, device=red_device)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
+
+    def phase_ms(prefix_is_count):
+        return sum(ms / timed * (launches / args.steps) for nm, (timed, launches, ms) in prof.items()
+                   if timed and nm.startswith("pc_c") == prefix_is_count)
+    # one row per rank: what it held and how long its steps took (imbalance shows here, not in the max)
+    mine = torch.tensor([rank, x_lo, x_hi, n, tests_local, pairs_local, elapsed / args.steps * 1e3,
+                         phase_ms(False), phase_ms(True)], dtype=torch.float64, device=red_device)
+    rows = [torch.zeros_like(mine) for _ in range(world)]
     if world > 1:
-        dist.all_reduce(agg)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        assert int(total.item()) == int(agg[0].item()), "all-reduced count differs from the sum of rank counts"
-    pairs, tests, points_held = (int(v) for v in agg.tolist())
-    elapsed = float(tmax.item())
-    ms_per_step = elapsed / args.steps * 1e3
+        dist.all_gather(rows, mine)
+    else:
+        rows = [mine]
+    ranks = [{"rank": int(r[0]), "x_lo": int(r[1]), "x_hi": int(r[2]), "points_held": int(r[3]), "tests": int(r[4]),
+              "pairs": int(r[5]), "ms_per_step": float(r[6]), "binning_ms": float(r[7]), "pair_test_ms": float(r[8])}
+             for r in (t.tolist() for t in rows)]
+    pairs = sum(r["pairs"] for r in ranks)
+    tests = sum(r["tests"] for r in ranks)
+    points_held = sum(r["points_held"] for r in ranks)
+    if world > 1:
+        assert int(total.item()) == pairs, "all-reduced count differs from the sum of rank counts"
+    ms_per_step = max(r["ms_per_step"] for r in ranks)
+    elapsed = ms_per_step * 1e-3 * args.steps
 
     if rank == 0:
         # ---- per-kernel timings (HIP events on the launch stream, inside the timed region) ----
@@ -208,7 +254,7 @@ def main():
         dk = kernels[dom]
         # HBM traffic per launch of the dominant kernel: not measurable from inside this process; taken from
         # the committed rocprofv3 --pmc passes of the same workload (profiles/*traffic_<workload>.json,
-        # produced by tools/pmc_to_traffic.py, gfx950 FETCH_SIZE correction applied there), else null
+        # produced by tools/pmc_to_traffic.py from the request counters, see there), else null
         traffic = None
         if world == 1 and not args.points:
             import glob
@@ -219,12 +265,22 @@ def main():
                 if tk:
                     traffic = tk["hbm_bytes"] / 1e9
                     dk["traffic_source"] = os.path.relpath(files[-1], ROOT)
-        roofline = {
-            "kernel": dom, "bound": "hbm", "achieved": dk.get("achieved_gbs"), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": (dk.get("achieved_gbs") or 0.0) / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_unit": "GB per launch (PMC, committed profile)", "algorithmic_gb": dk.get("algorithmic_gb"),
-            "avg_launch_ms": dk["avg_ms"],
-        }
+        # The dominant kernel against the roofline that bounds it.  A pair-test kernel is priced both ways --
+        # 9 unfused binary32 operations per reference test against the vector peak without FMA credit, and its
+        # compulsory bytes (12 N + 4 C) against HBM -- and the larger fraction names the bound.
+        hbm_frac = (dk.get("achieved_gbs") or 0.0) / HBM_PEAK_GBS
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": dk.get("achieved_gbs"), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": hbm_frac}
+        if dom.startswith("pc_c"):
+            valu_tops = 9 * tests_local / (dk["avg_ms"] * 1e-3) / 1e12
+            roofline["hbm_leg"] = {"achieved_gbs": dk.get("achieved_gbs"), "frac": hbm_frac}
+            roofline["valu_leg"] = {"achieved_tops": valu_tops, "peak_tops": VALU_NOFMA_TOPS, "frac": valu_tops / VALU_NOFMA_TOPS,
+                                    "ops_per_test": 9}
+            if valu_tops / VALU_NOFMA_TOPS > hbm_frac:
+                roofline.update({"bound": "valu", "achieved": valu_tops, "peak": VALU_NOFMA_TOPS, "unit": "TFLOP/s",
+                                 "frac": valu_tops / VALU_NOFMA_TOPS})
+        roofline.update({"traffic": traffic, "traffic_unit": "GB per launch (PMC, committed profile)",
+                         "algorithmic_gb": dk.get("algorithmic_gb"), "avg_launch_ms": dk["avg_ms"]})
         binning_alg_gb = (44 * n + 8 * (layers + 1) * 403 * 403) / 1e9
         out = {
             "metric": "pairs-tested/s (reference dist2 evaluations covered per second, whole hot path: keys+binning+pair test)",
@@ -236,22 +292,75 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "points": total_points, "points_held_incl_halo": points_held,
                        "cutoff": 0.05, "slabs": slabs, "slab_cuts": cuts, "seed": args.seed,
-                       "generator": args.generate, "generator_s": round(t_gen, 2)},
+                       "generator": args.generate, "generator_s": round(t_gen, 2), "backend": args.backend if world > 1 else None},
             "pairs": pairs, "tests": tests,
             "pairs_tested_per_s_pair_test_kernel_only": (tests_local / (cnt_ms * 1e-3)) if cnt_ms else None,
             "binning_ms": bin_ms, "pair_test_ms": cnt_ms,
-            "binning_roofline": {"algorithmic_gb": binning_alg_gb,
-                                 "achieved_gbs": binning_alg_gb / (bin_ms * 1e-3) if bin_ms else None,
-                                 "frac_of_hbm_peak": binning_alg_gb / (bin_ms * 1e-3) / HBM_PEAK_GBS if bin_ms else None},
+            "binning_roofline": {"bound": "hbm", "algorithmic_gb": binning_alg_gb,
+                                 "achieved": binning_alg_gb / (bin_ms * 1e-3) if bin_ms else None, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s",
+                                 "frac": binning_alg_gb / (bin_ms * 1e-3) / HBM_PEAK_GBS if bin_ms else None,
+                                 "note": "all binning kernels of a step together against 44 N + 8 C bytes"},
             "pair_test_valu_frac": (9 * tests_local / (cnt_ms * 1e-3) / 1e12 / VALU_NOFMA_TOPS) if cnt_ms else None,
+            "ranks": ranks,
             "kernels": kernels,
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline and not args.as_rank:
             out["cpu_baseline"] = cpu_baseline(psa, ht, st, torch, kind, args.seed, total_points, sigma, device)
+            if not args.no_e2e_full and not args.points and args.workload in ("uniform100m", "blobs100m"):
+                del xyz
+                out["cpu_baseline"]["end_to_end_full"] = end_to_end_full(ht, kind, args.seed, total_points, sigma, pairs)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def end_to_end_full(ht, kind, seed, total_points, sigma, hip_pairs):
+    """The whole workload as a text file through both programs, process start to count printed: the
+    reference binary once (it takes a quarter of a minute at 100 M points) and the product's host program
+    twice (best run).  Both counts are compared with the count of the timed steps."""
+    cores = ht.host_threads()
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "main_timer")
+    if not (os.path.exists(ref_bin) and os.path.exists(ht.MAIN_PATH)):
+        return {"error": "oracle/_ref/main_timer or the host program is not built"}
+    tmp = tempfile.mkdtemp(prefix="pcbench_full_", dir=os.environ.get("PAIRCOUNT_TMP") or None)
+    path = os.path.join(tmp, "full.xyz")
+    try:
+        t0 = time.time()
+        npts = ht.generate_text(path, kind, seed, total_points, sigma)
+        t_write = time.time() - t0
+        out = {"points": npts, "file_bytes": os.path.getsize(path), "threads": cores, "file_written_s": round(t_write, 2)}
+        best = None
+        for _ in range(2):
+            t1 = time.time()
+            g = subprocess.run([ht.MAIN_PATH, "-f", path, "-p", str(cores)], capture_output=True, text=True,
+                               timeout=600, env=dict(os.environ, PAIRCOUNT_TIMER="1"))
+            w = time.time() - t1
+            if g.returncode != 0:
+                return dict(out, error="host program failed rc=%d: %s" % (g.returncode, g.stderr[-200:]))
+            if best is None or w < best[0]:
+                best = (w, g)
+        gph = {m.group(1): float(m.group(2)) / 1e6 for m in re.finditer(r"(\w[\w()]*):\s+(\d+) us", best[1].stderr)}
+        out.update({"gpu_host_program_wall_s": best[0], "gpu_phases_s": gph, "gpu_count": int(best[1].stdout.strip())})
+        t1 = time.time()
+        r = subprocess.run([ref_bin, "-f", path, "-p", str(cores), "-c", str(cores)], capture_output=True, text=True, timeout=900)
+        wall = time.time() - t1
+        if r.returncode != 0:
+            return dict(out, error="reference binary failed rc=%d: %s" % (r.returncode, r.stderr[-200:]))
+        phases = {m.group(1): int(m.group(2)) / 1e6 for m in re.finditer(r"(\w+):\s+(\d+) us", r.stdout)}
+        count = int([ln for ln in r.stdout.splitlines() if ln.strip().isdigit()][-1])
+        out.update({"reference_wall_s": wall, "reference_phases_s": phases, "reference_count": count,
+                    "counts_equal": count == out["gpu_count"] == hip_pairs,
+                    "speedup": wall / best[0],
+                    "note": "process start to count printed on the same file; reference one run, host program best of two"})
+        return out
+    finally:
+        try:
+            os.remove(path)
+            os.rmdir(tmp)
+        except OSError:
+            pass
 
 
 def cpu_baseline(psa, ht, st, torch, kind, seed, total_points, sigma, device):

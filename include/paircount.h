@@ -97,7 +97,9 @@ void pc_destroy(pc_context *ctx);
 
 /* ---- stateless device-pointer stages (no allocation, no host sync) ------- */
 /* These launch on `stream` and return immediately; all pointers are device
-   memory.  They are what the streaming interface runs internally and what the
+   memory of the CURRENT device: the caller makes the data's device current
+   (hipSetDevice) before the call -- the per-device work areas and launch sizes
+   are looked up by the current device, not by the pointers.  They are what the streaming interface runs internally and what the
    parity tests and the benchmark drive directly. */
 
 /* Bytes of scratch pc_bin_device / pc_count_pairs_device need for n points. */

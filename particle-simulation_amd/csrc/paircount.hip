@@ -3,6 +3,7 @@
 #include "../../include/paircount.h"
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <pthread.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -41,12 +42,14 @@ extern "C" const char *pc_last_error(void) { return g_err; }
 extern "C" const char *pc_version(void) { return "1.0 gfx950"; }
 
 // ---------------------------------------------------------------- variants --
-static int g_variant_bin = 1;     // 0 = atomic counting sort, 1 = LDS-staged three-level bucket sort
+// Process-wide measurement knobs (pc_set_variant): atomics, so that a host thread changing one while
+// another thread launches is a defined read of the old or the new value, never a torn one.
+static std::atomic<int> g_variant_bin{1};     // 0 = atomic counting sort, 1 = LDS-staged three-level bucket sort
 // 0 = global memory, 1 = LDS-tiled strips, 2 = wave per pencil, 3 = candidate-parallel groups,
 // 4 = by density: 0 below 0.8 points per cell of the slab on average, else 3
-static int g_variant_count = 4;
-static int g_heavy = PC_G_HEAVY_CAP;      // capacity of the list of over-full cells' home-particle chunks (0: never listed)
-static int g_segments = PC_G_SEG_CAP;   // capacity of the heavy-pencil segment list (0: pencils are never cut)
+static std::atomic<int> g_variant_count{4};
+static std::atomic<int> g_heavy{PC_G_HEAVY_CAP};    // capacity of the list of over-full cells' home-particle chunks (0: never listed)
+static std::atomic<int> g_segments{PC_G_SEG_CAP};  // capacity of the heavy-pencil segment list (0: pencils are never cut)
 
 extern "C" int pc_set_variant(const char *name, int value)
 {
@@ -87,7 +90,9 @@ struct pc_prof_slot {
     unsigned long long launches;
 };
 static pc_prof_slot g_prof[PC_PROF_SLOTS];
-static int g_prof_n = 0, g_prof_on = 0;
+static int g_prof_n = 0;
+static std::atomic<int> g_prof_on{0};
+static pthread_mutex_t g_prof_lock = PTHREAD_MUTEX_INITIALIZER;   // slots and rings; taken only while profiling is on
 
 static pc_prof_slot *prof_slot(const char *name)
 {
@@ -104,18 +109,21 @@ struct pc_prof_scope {
     int idx = -1;
     pc_prof_scope(const char *name, hipStream_t stream) : st(stream)
     {
-        if (!g_prof_on) return;
+        if (!g_prof_on.load(std::memory_order_relaxed)) return;
+        pthread_mutex_lock(&g_prof_lock);
         s = prof_slot(name);
-        if (!s) return;
-        s->launches++;
-        if (s->used == PC_PROF_RING) return;
-        if (s->used == s->created) {
-            if (hipEventCreate(&s->ev[s->created][0]) != hipSuccess) return;
-            if (hipEventCreate(&s->ev[s->created][1]) != hipSuccess) return;
-            s->created++;
+        if (s) {
+            s->launches++;
+            if (s->used < PC_PROF_RING) {
+                if (s->used == s->created && hipEventCreate(&s->ev[s->created][0]) == hipSuccess) {
+                    if (hipEventCreate(&s->ev[s->created][1]) == hipSuccess) s->created++;
+                    else (void)hipEventDestroy(s->ev[s->created][0]);
+                }
+                if (s->used < s->created) idx = s->used++;
+            }
         }
-        idx = s->used++;
-        (void)hipEventRecord(s->ev[idx][0], st);
+        pthread_mutex_unlock(&g_prof_lock);
+        if (idx >= 0) (void)hipEventRecord(s->ev[idx][0], st);
     }
     ~pc_prof_scope()
     {
@@ -131,9 +139,11 @@ struct pc_prof_scope {
 
 extern "C" int pc_profile_enable(int on)
 {
-    g_prof_on = on != 0;
+    pthread_mutex_lock(&g_prof_lock);
     if (on)
         for (int i = 0; i < g_prof_n; i++) { g_prof[i].used = 0; g_prof[i].launches = 0; }
+    g_prof_on.store(on != 0, std::memory_order_relaxed);
+    pthread_mutex_unlock(&g_prof_lock);
     return PC_OK;
 }
 
@@ -142,6 +152,10 @@ extern "C" int pc_profile_read(char *buf, size_t buflen)
     if (!buf || buflen == 0) return pc_fail(PC_ERR_ARG, "pc_profile_read: null buffer");
     size_t off = 0;
     buf[0] = 0;
+    struct prof_turn {
+        prof_turn() { pthread_mutex_lock(&g_prof_lock); }
+        ~prof_turn() { pthread_mutex_unlock(&g_prof_lock); }
+    } turn;
     for (int i = 0; i < g_prof_n; i++) {
         pc_prof_slot &s = g_prof[i];
         double total = 0;
@@ -159,10 +173,10 @@ extern "C" int pc_profile_read(char *buf, size_t buflen)
 }
 
 // ------------------------------------------------------------------ stages --
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static constexpr size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static const uint64_t PC_MAX_POINTS = 0xFFFFFFF0ull;   // slots are uint32
 
-static inline uint32_t scan_tiles(uint64_t m) { return (uint32_t)((m + PC_SCAN_TILE - 1) / PC_SCAN_TILE); }
+static constexpr uint32_t scan_tiles(uint64_t m) { return (uint32_t)((m + PC_SCAN_TILE - 1) / PC_SCAN_TILE); }
 static inline int grid_for(uint64_t n, int tpb, int cap);
 
 // Workgroups of `kernel` that are resident on the current device at once (the grid
@@ -180,14 +194,14 @@ static int resident_blocks(K kernel, int tpb, int *slot)
 }
 
 // uint32 counters of the LDS variant, after its N*12-byte temp array
-static inline size_t lds_ws_counters(uint64_t n)
+static constexpr size_t lds_ws_counters(uint64_t n)
 {
     return (size_t)PC_L_NREP * PC_L_BINS + (size_t)PC_L_NREP * PC_L_PSTRIDE + PC_L_BINS + (size_t)PC_L_NREP * PC_L_BINS + PC_L_BINS +
            ((n + PC_L_TILE - 1) / PC_L_TILE + PC_L_BINS) + (PC_L_NPENCILS + 1) + (size_t)PC_L_NREP * PC_L_PSTRIDE +
            8 + PC_L_NPENCILS;
 }
 
-extern "C" size_t pc_workspace_bytes(uint64_t n)
+static constexpr size_t workspace_bytes_for(uint64_t n)
 {
     size_t keys = align_up((size_t)n * 4 + 4, 256);
     size_t sums = align_up((size_t)scan_tiles(PC_NCELLS + 2) * 4, 256);
@@ -195,6 +209,8 @@ extern "C" size_t pc_workspace_bytes(uint64_t n)
     size_t v1 = align_up((size_t)n * 12 + 16, 256) + align_up(lds_ws_counters(n) * 4, 256) + align_up((size_t)n * 2 + 16, 256) + 256;
     return v0 > v1 ? v0 : v1;
 }
+
+extern "C" size_t pc_workspace_bytes(uint64_t n) { return workspace_bytes_for(n); }
 
 static pc_lds_ws carve_lds_ws(void *ws, uint64_t n)
 {
@@ -413,10 +429,11 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
         unsigned int *queue = nullptr;
         int rc2 = count_queue(&queue);
         if (rc2) return rc2;
+        const uint32_t seg_cap = (uint32_t)g_segments.load(), heavy_cap = (uint32_t)g_heavy.load();   // one read each per call
         PC_HIP(hipMemsetAsync(queue, 0, PC_G_FLAGS * sizeof(unsigned int), (hipStream_t)stream));   // all counters
         const dim3 plan_grid(((x_hi - x_lo) * PC_NLAYERS + 255) / 256);
         PC_LAUNCH("pc_c3_plan", pc_c3_plan, plan_grid, dim3(256), (hipStream_t)stream, d_cell_start, x_lo, x_hi, queue,
-                  (uint32_t)g_segments);
+                  seg_cap);
         // as many workgroups as are resident at once (registers and LDS decide: asked of the runtime, once)
         static int resident_on[64];               // per device ordinal (count_queue has checked the range)
         int dev = 0;
@@ -433,12 +450,12 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
         const int want = resident, most = ((x_hi - x_lo) * PC_NLAYERS + PC_G_WAVES - 1) / PC_G_WAVES;
         const int grid = ((want < most ? want : most) + 7) / 8 * 8;
         PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
-                  d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, (uint32_t)g_segments, (uint32_t)g_heavy,
+                  d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap,
                   (unsigned long long *)d_npairs);
         // the home particles of over-full cells that the waves listed instead of processing (normally none:
         // the workgroups then return at once)
         PC_LAUNCH("pc_c3_heavy", pc_c3_heavy, dim3(resident >= 2048 ? 2048 : resident), dim3(PC_G_HEAVY_CHUNK), (hipStream_t)stream,
-                  d_sorted_xyz, d_cell_start, queue, (uint32_t)g_heavy, (unsigned long long *)d_npairs);
+                  d_sorted_xyz, d_cell_start, queue, heavy_cap, (unsigned long long *)d_npairs);
     } else if (variant == 2) {
         const int grid = 8 * (x_hi - x_lo) * PC_W_WG_PER_BAND;
         PC_LAUNCH("pc_c2_count_waves", pc_c2_count_waves, dim3(grid), dim3(PC_W_WAVES * 64), (hipStream_t)stream,
@@ -492,7 +509,11 @@ struct pc_context {
     pthread_mutex_t reserve;    // serialises slot reservation
     float *d_xyz;
     uint64_t cap, size;
-    int finished;
+    int finished;               // appends are closed (set by the first pc_finish)
+    int done;                   // pc_finish has run to its end: finish_rc, npairs, ntests, ms are final
+    int finish_rc;              // what that pc_finish returned; later calls return it again
+    int append_rc;              // first failure of a copy into a reserved range (the range then holds no points)
+    char finish_msg[256], append_msg[256];
     int64_t npairs, ntests;
     float ms[2];
 };
@@ -580,6 +601,20 @@ static int reserve_slots(pc_context *c, uint64_t n, uint64_t *off)
     }
 }
 
+// A copy into an already reserved range failed: the range stays in the array but holds
+// no points, so the context can no longer produce a count.  pc_finish returns this error.
+static int append_failed(pc_context *c, const char *fmt, const char *what)
+{
+    const int rc = pc_fail(PC_ERR_HIP, fmt, what);
+    pthread_mutex_lock(&c->reserve);
+    if (!c->append_rc) {
+        c->append_rc = rc;
+        snprintf(c->append_msg, sizeof c->append_msg, "%s", g_err);
+    }
+    pthread_mutex_unlock(&c->reserve);
+    return rc;
+}
+
 extern "C" int pc_append(pc_context *c, const float *xyz, uint64_t n)
 {
     if (!c) return pc_fail(PC_ERR_ARG, "pc_append: null context");
@@ -591,7 +626,7 @@ extern "C" int pc_append(pc_context *c, const float *xyz, uint64_t n)
     if (rc) return rc;
     hipError_t e = hipMemcpy(c->d_xyz + 3 * off, xyz, n * 12, hipMemcpyHostToDevice);
     pthread_rwlock_unlock(&c->lock);
-    if (e != hipSuccess) return pc_fail(PC_ERR_HIP, "pc_append: hipMemcpy: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return append_failed(c, "pc_append: hipMemcpy: %s", hipGetErrorString(e));
     return PC_OK;
 }
 
@@ -625,7 +660,7 @@ extern "C" int pc_append_device(pc_context *c, const float *d_xyz, uint64_t n, v
     hipError_t e = hipMemcpyAsync(c->d_xyz + 3 * off, d_xyz, n * 12, hipMemcpyDeviceToDevice, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     pthread_rwlock_unlock(&c->lock);
-    if (e != hipSuccess) return pc_fail(PC_ERR_HIP, "pc_append_device: copy: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return append_failed(c, "pc_append_device: copy: %s", hipGetErrorString(e));
     return PC_OK;
 }
 
@@ -644,7 +679,7 @@ struct finish_bufs {
     void *ws = nullptr;
     uint64_t *res = nullptr;     // [0] pairs, [1] tests
     int32_t *status = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // binning start/end, pair test start/end
     ~finish_bufs()
     {
         if (sorted) (void)hipFree(sorted);
@@ -664,17 +699,9 @@ static pthread_mutex_t g_finish_lock[64] = {
 #undef PC_M4
 };
 
-extern "C" int pc_finish(pc_context *c, int64_t *npairs)
+static int finish_work(pc_context *c)
 {
-    if (!c || !npairs) return pc_fail(PC_ERR_ARG, "pc_finish: null pointer");
-    pthread_rwlock_wrlock(&c->lock);
-    if (c->finished) {
-        pthread_rwlock_unlock(&c->lock);
-        *npairs = c->npairs;
-        return PC_OK;
-    }
-    c->finished = 1;
-    pthread_rwlock_unlock(&c->lock);
+    if (c->append_rc) return pc_fail(c->append_rc, "an earlier append failed (%s): the context holds no usable point set", c->append_msg);
     PC_HIP(hipSetDevice(c->device));
     const uint64_t n = c->size;
     finish_bufs b;
@@ -699,30 +726,64 @@ extern "C" int pc_finish(pc_context *c, int64_t *npairs)
                         c->x_hi < PC_NLAYERS ? c->x_hi : PC_NBB - 1);
     if (rc) return rc;
     PC_HIP(hipEventRecord(b.ev[1], s));
+    // a point outside the grid leaves the sorted array and the table incomplete: stop before the pair test
+    int32_t host_status = 0;
+    PC_HIP(hipMemcpyAsync(&host_status, b.status, 4, hipMemcpyDeviceToHost, s));
+    PC_HIP(hipStreamSynchronize(s));
+    if (host_status & 1)
+        return pc_fail(PC_ERR_DOMAIN, "a coordinate lies outside the reference's domain (-10,10)");
+    PC_HIP(hipEventRecord(b.ev[2], s));
     rc = pc_count_sorted_device(b.sorted, b.table, n, c->x_lo, c->x_hi, b.res, s);
     if (rc) return rc;
-    PC_HIP(hipEventRecord(b.ev[2], s));
+    PC_HIP(hipEventRecord(b.ev[3], s));
     rc = pc_count_tests_device(b.table, c->x_lo, c->x_hi, b.res + 1, s);
     if (rc) return rc;
     uint64_t host_res[2];
-    int32_t host_status = 0;
     PC_HIP(hipMemcpyAsync(host_res, b.res, 16, hipMemcpyDeviceToHost, s));
-    PC_HIP(hipMemcpyAsync(&host_status, b.status, 4, hipMemcpyDeviceToHost, s));
     PC_HIP(hipStreamSynchronize(s));
     PC_HIP(hipEventElapsedTime(&c->ms[0], b.ev[0], b.ev[1]));
-    PC_HIP(hipEventElapsedTime(&c->ms[1], b.ev[1], b.ev[2]));
-    if (host_status & 1)
-        return pc_fail(PC_ERR_DOMAIN, "a coordinate lies outside the reference's domain (-10,10)");
+    PC_HIP(hipEventElapsedTime(&c->ms[1], b.ev[2], b.ev[3]));
     c->npairs = (int64_t)host_res[0];
     c->ntests = (int64_t)host_res[1];
-    *npairs = c->npairs;
     return PC_OK;
+}
+
+// The first call closes the context for appends, does the work and records its
+// outcome; every later call (and pc_tests / pc_phase_ms) reports that outcome
+// again -- a failed finish stays a failure, it never turns into a count of 0.
+extern "C" int pc_finish(pc_context *c, int64_t *npairs)
+{
+    if (!c || !npairs) return pc_fail(PC_ERR_ARG, "pc_finish: null pointer");
+    pthread_rwlock_wrlock(&c->lock);            // waits for copies in flight; held to the end: one finish at a time
+    c->finished = 1;
+    if (!c->done) {
+        c->finish_rc = finish_work(c);
+        if (c->finish_rc) snprintf(c->finish_msg, sizeof c->finish_msg, "%s", g_err);
+        c->done = 1;
+    }
+    const int rc = c->finish_rc;
+    if (rc) pc_fail(rc, "%s", c->finish_msg);
+    else *npairs = c->npairs;
+    pthread_rwlock_unlock(&c->lock);
+    return rc;
+}
+
+// outcome of the context's pc_finish for the calls that read its results
+static int finished_ok(pc_context *c, const char *who)
+{
+    pthread_rwlock_rdlock(&c->lock);
+    const int done = c->done, rc = c->finish_rc;
+    if (done && rc) pc_fail(rc, "%s", c->finish_msg);
+    pthread_rwlock_unlock(&c->lock);
+    if (!done) return pc_fail(PC_ERR_STATE, "%s before pc_finish", who);
+    return rc;
 }
 
 extern "C" int pc_tests(pc_context *c, int64_t *ntests)
 {
     if (!c || !ntests) return pc_fail(PC_ERR_ARG, "pc_tests: null pointer");
-    if (!c->finished) return pc_fail(PC_ERR_STATE, "pc_tests before pc_finish");
+    const int rc = finished_ok(c, "pc_tests");
+    if (rc) return rc;
     *ntests = c->ntests;
     return PC_OK;
 }
@@ -730,7 +791,8 @@ extern "C" int pc_tests(pc_context *c, int64_t *ntests)
 extern "C" int pc_phase_ms(pc_context *c, float ms[2])
 {
     if (!c || !ms) return pc_fail(PC_ERR_ARG, "pc_phase_ms: null pointer");
-    if (!c->finished) return pc_fail(PC_ERR_STATE, "pc_phase_ms before pc_finish");
+    const int rc = finished_ok(c, "pc_phase_ms");
+    if (rc) return rc;
     ms[0] = c->ms[0];
     ms[1] = c->ms[1];
     return PC_OK;

@@ -27,7 +27,12 @@ pc_c0_count_global(const float *__restrict__ pts, const uint32_t *__restrict__ T
         const pt3 *P = reinterpret_cast<const pt3 *>(pts);
         const pt3 me = P[p];
         const float x = me.x, y = me.y, z = me.z;
-        uint32_t c = pc_key(pc_cell_index(x), pc_cell_index(y), pc_cell_index(z));
+        // Slots the binning left unwritten (it drops out-of-domain points and flags the status word) still
+        // hold whatever the scratch use of the array put there: a point outside the grid is never a home
+        // particle, and its key must not index the table.
+        const int ci = pc_cell_index(x), cj = pc_cell_index(y), ck = pc_cell_index(z);
+        if (!pc_in_grid(ci, cj, ck)) continue;
+        uint32_t c = pc_key(ci, cj, ck);
         uint32_t cnt = 0;
         // the five candidate ranges: same cell (later slots) with cell c+1 = slots (p, T[c+2]), then the
         // three-cell runs of the four neighbour pencils; all ten table reads are issued before any is used

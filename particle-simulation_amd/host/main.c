@@ -14,10 +14,20 @@
  * A data file whose name ends in ".f32" is taken as the parsed form of such a
  * file -- packed binary32 x,y,z triples -- and appended without tokenizing
  * (kernel-side runs at sizes where the text would be tens of gigabytes).
+ * One addition to the reference's command line: -g NUM (or PAIRCOUNT_GPUS=NUM)
+ * cuts the x range into NUM slabs, one library context per slab, slab s on GPU s
+ * (PAIRCOUNT_DEVICES="0,0,1" names the GPU of each slab instead;
+ * PAIRCOUNT_CUTS="0,170,400" the first x layer of each slab and the end).  The parser
+ * threads then route every point to the slab that owns its x layer -- and the first
+ * layer of a slab also to the slab below it, whose pairs reach one layer up
+ * (every neighbour offset of the reference has dx in {0,+1}, main.c:195-209) -- the
+ * slabs are finished concurrently and their counts added: the fold of the
+ * counter threads' totals at main.c:231.  Without -g nothing changes.
  * With PAIRCOUNT_TIMER=1 in the environment the four phase times the
  * reference's -DTIMER build prints are written to stderr.
  */
 #define _GNU_SOURCE
+#include <errno.h>
 #include <fcntl.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -32,15 +42,28 @@
 #include "xyz_parse.h"
 
 #define BLOCK_POINTS 65536
+#define MAX_SLABS 64
+#define LAYERS PC_NLAYERS
+
+/* the x slabs of a run (one slab, the whole grid, unless -g asks for more) */
+typedef struct {
+    int n;                           /* slabs */
+    int cut[MAX_SLABS + 1];          /* slab s owns x layers [cut[s], cut[s+1]) */
+    int device[MAX_SLABS];
+    pc_context *ctx[MAX_SLABS];
+    unsigned char owner[LAYERS];     /* layer -> slab */
+    uint32_t block_points;           /* capacity of one (thread, slab) block */
+} slab_set;
 
 typedef struct {
     const char *file;
     size_t size;
     int t, nt;
-    pc_context *ctx;
+    const slab_set *slabs;
     int status;              /* 0 ok, 1 tokenizer error, 2 library error */
     double append_us;        /* time this thread spent inside pc_append */
-    float *block;            /* this thread's page-locked block of BLOCK_POINTS points */
+    float *block;            /* this thread's page-locked blocks: one of block_points points per slab */
+    uint32_t fill[MAX_SLABS];
     int binary;              /* the file holds float triples, not text */
     char msg[256];
 } worker;
@@ -52,25 +75,68 @@ static double now_us(void)
     return t.tv_sec * 1e6 + t.tv_usec;
 }
 
-static int append_block(worker *w, const float *block, uint64_t n)
+static int append_block(worker *w, int slab, const float *block, uint64_t n)
 {
     const double t = now_us();
-    const int rc = pc_append(w->ctx, block, n);
+    const int rc = pc_append(w->slabs->ctx[slab], block, n);
     w->append_us += now_us() - t;
     if (rc != PC_OK) { w->status = 2; snprintf(w->msg, sizeof w->msg, "%s", pc_last_error()); }
     return rc;
 }
 
-/* ".f32" input: thread t appends its share of the triples straight from the mapping */
+/* one point into this thread's block of slab s; a full block is appended */
+static inline int put_point(worker *w, int s, const float *pt)
+{
+    float *blk = w->block + (size_t)s * w->slabs->block_points * 3;
+    memcpy(blk + 3 * (size_t)w->fill[s], pt, 12);
+    if (++w->fill[s] == w->slabs->block_points) {
+        w->fill[s] = 0;
+        return append_block(w, s, blk, w->slabs->block_points);
+    }
+    return PC_OK;
+}
+
+/* Several slabs: the point goes to the owner of its x layer (the reference's cell
+   formula, main.c:134) and, when that layer is the first of a slab, also to the slab
+   below as its +x halo.  A point outside the grid goes to slab 0, whose pc_finish
+   reports it. */
+static inline int route_point(worker *w, const float *pt)
+{
+    const slab_set *S = w->slabs;
+    const double q = ((double)pt[0] + 10.0) / 0.05;
+    const int cx = q >= 0.0 && q < (double)LAYERS ? (int)q : -1;
+    if (cx < 0) return put_point(w, 0, pt);
+    const int s = S->owner[cx];
+    if (put_point(w, s, pt) != PC_OK) return -1;
+    if (s > 0 && cx == S->cut[s]) return put_point(w, s - 1, pt);
+    return PC_OK;
+}
+
+static void flush_blocks(worker *w)
+{
+    for (int s = 0; s < w->slabs->n && !w->status; s++)
+        if (w->fill[s]) {
+            append_block(w, s, w->block + (size_t)s * w->slabs->block_points * 3, w->fill[s]);
+            w->fill[s] = 0;
+        }
+}
+
+/* ".f32" input: thread t takes its share of the triples straight from the mapping */
 static void append_binary_share(worker *w)
 {
     const uint64_t total = w->size / 12;
     const uint64_t first = total * (uint64_t)w->t / (uint64_t)w->nt, last = total * (uint64_t)(w->t + 1) / (uint64_t)w->nt;
     const float *pts = (const float *)w->file;
-    for (uint64_t i = first; i < last; i += 16 * BLOCK_POINTS) {
-        const uint64_t m = last - i < 16 * BLOCK_POINTS ? last - i : 16 * BLOCK_POINTS;
-        if (append_block(w, pts + 3 * i, m) != PC_OK) return;
+    if (w->slabs->n == 1) {
+        for (uint64_t i = first; i < last; i += 16 * BLOCK_POINTS) {
+            const uint64_t m = last - i < 16 * BLOCK_POINTS ? last - i : 16 * BLOCK_POINTS;
+            if (append_block(w, 0, pts + 3 * i, m) != PC_OK) return;
+        }
+        return;
     }
+    for (uint64_t i = first; i < last; i++)
+        if (route_point(w, pts + 3 * i) != PC_OK) return;
+    flush_blocks(w);
 }
 
 static void *parser_thread(void *arg)
@@ -80,6 +146,21 @@ static void *parser_thread(void *arg)
     float *block = w->block;
     const char *p, *stop;
     xyz_thread_range(w->file, w->size, w->t, w->nt, &p, &stop);
+    if (w->slabs->n > 1) {
+        while (p < stop) {
+            int err = 0;
+            float pt[3];
+            p = xyz_parse_line_bounded(p, w->file + w->size, pt, &err);
+            if (err) {
+                w->status = 1;
+                snprintf(w->msg, sizeof w->msg, err == XYZ_ERR_NODOT ? "*str != '.'" : "sci_exp > 0");
+                return NULL;
+            }
+            if (route_point(w, pt) != PC_OK) return NULL;
+        }
+        flush_blocks(w);
+        return NULL;
+    }
     uint64_t n = 0;
     while (p < stop) {
         int err = 0;
@@ -90,18 +171,51 @@ static void *parser_thread(void *arg)
             break;
         }
         if (++n == BLOCK_POINTS) {
-            if (append_block(w, block, n) != PC_OK) break;
+            if (append_block(w, 0, block, n) != PC_OK) break;
             n = 0;
         }
     }
-    if (!w->status && n) append_block(w, block, n);
+    if (!w->status && n) append_block(w, 0, block, n);
+    return NULL;
+}
+
+/* "a,b,c" -> out[0..]; returns how many numbers were read (at most cap) */
+static int parse_int_list(const char *s, int *out, int cap)
+{
+    int n = 0;
+    while (s && *s && n < cap) {
+        char *e;
+        const long v = strtol(s, &e, 10);
+        if (e == s) break;
+        out[n++] = (int)v;
+        s = *e == ',' ? e + 1 : e;
+    }
+    return n;
+}
+
+typedef struct {
+    pc_context *ctx;
+    int64_t npairs, tests;
+    float ms[2];
+    int rc;
+    char msg[256];
+} finisher;
+
+static void *finish_thread(void *arg)
+{
+    finisher *f = (finisher *)arg;
+    f->rc = pc_finish(f->ctx, &f->npairs);
+    if (f->rc != PC_OK) { snprintf(f->msg, sizeof f->msg, "%s", pc_last_error()); return NULL; }
+    pc_phase_ms(f->ctx, f->ms);
+    pc_tests(f->ctx, &f->tests);
     return NULL;
 }
 
 static void usage(char **argv)
 {
-    printf("Usage: %s -f <data file> [-p NUM] [-c NUM]\n", argv[0]);
+    printf("Usage: %s -f <data file> [-p NUM] [-c NUM] [-g NUM]\n", argv[0]);
     puts("\t-c Num\tAccepted for compatibility (pairs are counted on the GPU).");
+    puts("\t-g Num\tNumber of GPUs (x slabs) to count on. Default is 1.");
     puts("\t-p Num\tNumber of threads to use while parsing. Default is 4.");
     puts("\t-h\tPrint this message and exit.");
 }
@@ -112,6 +226,7 @@ int main(int argc, char **argv)
     double t0 = now_us();
     const char *file_name = NULL;
     int pthreads = 4, cthreads = 4;
+    int gpus = getenv("PAIRCOUNT_GPUS") ? atoi(getenv("PAIRCOUNT_GPUS")) : 1;
     for (int i = 1; i < argc; i++) {
         if (argv[i][0] != '-') {
             printf("Unrecognized option \"%s\"\n", argv[i]);
@@ -124,6 +239,9 @@ int main(int argc, char **argv)
             break;
         case 'p':
             if (++i >= argc || (pthreads = atoi(argv[i])) <= 0) { perror("atoi"); return -1; }
+            break;
+        case 'g':
+            if (++i >= argc || (gpus = atoi(argv[i])) <= 0) { perror("atoi"); return -1; }
             break;
         case 'f':
             file_name = ++i < argc ? argv[i] : NULL;
@@ -138,6 +256,8 @@ int main(int argc, char **argv)
         }
     }
     (void)cthreads;
+    /* no -f: the reference passes its NULL file name to open(), which fails with EFAULT (main.c:297-300) */
+    if (!file_name) errno = EFAULT;
     int fd = file_name ? open(file_name, O_RDONLY) : -1;
     if (fd == -1) { perror("open"); return -1; }
     struct stat sb;
@@ -152,6 +272,8 @@ int main(int argc, char **argv)
         fprintf(stderr, "%s: %zu bytes is not a whole number of float triples\n", file_name, size);
         return -1;
     }
+    /* an empty text file: the reference's mmap of zero bytes fails (main.c:311-315) */
+    if (size == 0 && !binary) { errno = EINVAL; perror("mmap"); return -1; }
     const size_t page = (size_t)sysconf(_SC_PAGESIZE);
     const int mapped = size && (binary || (size % page) != 0);
     char *file = NULL;
@@ -170,11 +292,38 @@ int main(int argc, char **argv)
         file[size] = 0;
     }
 
-    int device = getenv("PAIRCOUNT_DEVICE") ? atoi(getenv("PAIRCOUNT_DEVICE")) : 0;
-    pc_context *ctx = NULL;
-    if (pc_create(&ctx, device, binary ? size / 12 + 1 : size / 24 + 1024) != PC_OK) {
-        fprintf(stderr, "pc_create: %s\n", pc_last_error());
+    /* the slabs: equal widths unless PAIRCOUNT_CUTS names them; slab s on GPU s unless PAIRCOUNT_DEVICES does */
+    static slab_set S;
+    if (gpus > MAX_SLABS) gpus = MAX_SLABS;
+    S.n = gpus;
+    for (int s = 0; s <= S.n; s++) S.cut[s] = LAYERS * s / S.n;
+    if (getenv("PAIRCOUNT_CUTS")) {
+        int c[MAX_SLABS + 1];
+        const int k = parse_int_list(getenv("PAIRCOUNT_CUTS"), c, MAX_SLABS + 1);
+        int ok = k == S.n + 1 && c[0] == 0 && c[S.n] == LAYERS;
+        for (int s = 0; ok && s < S.n; s++) ok = c[s] < c[s + 1];
+        if (!ok) { fprintf(stderr, "PAIRCOUNT_CUTS: need %d increasing layers from 0 to %d\n", S.n + 1, LAYERS); return -1; }
+        memcpy(S.cut, c, sizeof(int) * (size_t)(S.n + 1));
+    }
+    for (int s = 0; s < S.n; s++) {
+        S.device[s] = S.n == 1 && getenv("PAIRCOUNT_DEVICE") ? atoi(getenv("PAIRCOUNT_DEVICE")) : s;
+        for (int l = S.cut[s]; l < S.cut[s + 1]; l++) S.owner[l] = (unsigned char)s;
+    }
+    if (getenv("PAIRCOUNT_DEVICES") &&
+        parse_int_list(getenv("PAIRCOUNT_DEVICES"), S.device, S.n) != S.n) {
+        fprintf(stderr, "PAIRCOUNT_DEVICES: need %d device ordinals\n", S.n);
         return -1;
+    }
+    S.block_points = S.n == 1 ? BLOCK_POINTS : (BLOCK_POINTS / (uint32_t)S.n < 4096 ? 4096 : BLOCK_POINTS / (uint32_t)S.n);
+    const uint64_t expect = binary ? size / 12 + 1 : size / 24 + 1024;
+    for (int s = 0; s < S.n; s++) {
+        /* capacity hint: the slab's share of the points, with room for its halo layer and some imbalance */
+        const uint64_t hint = S.n == 1 ? expect : expect * (uint64_t)(S.cut[s + 1] - S.cut[s] + 2) / LAYERS + 4096;
+        if (pc_create(&S.ctx[s], S.device[s], hint) != PC_OK ||
+            (S.n > 1 && pc_set_slab(S.ctx[s], S.cut[s], S.cut[s + 1]) != PC_OK)) {
+            fprintf(stderr, "pc_create: %s\n", pc_last_error());
+            return -1;
+        }
     }
     if (timer) fprintf(stderr, "%16s:  %10.0f us\n", "init", now_us() - t0);
 
@@ -184,13 +333,14 @@ int main(int argc, char **argv)
     worker w[256];
     /* one page-locked allocation for all threads' blocks (page-locking is slow per call) */
     float *pinned = NULL;
-    if (size && pc_host_alloc((void **)&pinned, (uint64_t)pthreads * BLOCK_POINTS * 12) != PC_OK) {
+    const size_t thread_floats = (size_t)S.n * S.block_points * 3;
+    if (size && pc_host_alloc((void **)&pinned, (uint64_t)pthreads * thread_floats * 4) != PC_OK) {
         fprintf(stderr, "pc_host_alloc: %s\n", pc_last_error());
         return -1;
     }
     for (int t = 0; t < pthreads; t++) {
-        w[t] = (worker){.file = file, .size = size, .t = t, .nt = pthreads, .ctx = ctx, .status = 0,
-                        .block = pinned + (size_t)t * BLOCK_POINTS * 3, .binary = binary};
+        w[t] = (worker){.file = file, .size = size, .t = t, .nt = pthreads, .slabs = &S, .status = 0,
+                        .block = pinned + (size_t)t * thread_floats, .binary = binary};
         if (size == 0) continue;
         if (pthread_create(&th[t], NULL, parser_thread, &w[t]) != 0) { perror("pthread_create"); exit(-1); }
     }
@@ -212,22 +362,41 @@ int main(int argc, char **argv)
     }
 
     t0 = now_us();
-    int64_t npairs = 0;
-    if (pc_finish(ctx, &npairs) != PC_OK) {
-        fprintf(stderr, "pc_finish: %s\n", pc_last_error());
-        return -1;
+    /* flatten()+count() of the reference (main.c:331-335), one per slab, concurrently; the sum is its
+       fold of the counter threads' totals (main.c:231) */
+    static finisher fin[MAX_SLABS];
+    pthread_t fth[MAX_SLABS];
+    for (int s = 0; s < S.n; s++) {
+        fin[s].ctx = S.ctx[s];
+        if (S.n == 1) finish_thread(&fin[s]);
+        else if (pthread_create(&fth[s], NULL, finish_thread, &fin[s]) != 0) { perror("pthread_create"); exit(-1); }
+    }
+    int64_t npairs = 0, tests = 0;
+    float ms[2] = {0, 0};
+    for (int s = 0; s < S.n; s++) {
+        if (S.n > 1 && pthread_join(fth[s], NULL) != 0) { perror("pthread_join"); exit(-1); }
+        if (fin[s].rc != PC_OK) {
+            fprintf(stderr, "pc_finish: %s\n", fin[s].msg);
+            return -1;
+        }
+        npairs += fin[s].npairs;
+        tests += fin[s].tests;
+        for (int k = 0; k < 2; k++) if (fin[s].ms[k] > ms[k]) ms[k] = fin[s].ms[k];
     }
     printf("%ld\n", (long)npairs);
     if (timer) {
-        float ms[2] = {0, 0};
-        int64_t tests = 0;
-        pc_phase_ms(ctx, ms);
-        pc_tests(ctx, &tests);
-        fprintf(stderr, "%16s:  %10.0f us\n", "binning", ms[0] * 1e3);     /* reference phase "flatten" */
+        fprintf(stderr, "%16s:  %10.0f us\n", "binning", ms[0] * 1e3);     /* reference phase "flatten"; the slowest slab's */
         fprintf(stderr, "%16s:  %10.0f us\n", "count", ms[1] * 1e3);
         fprintf(stderr, "%16s:  %10.0f us\n", "finish(wall)", now_us() - t0);
         fprintf(stderr, "%16s:  %10ld\n", "tests", (long)tests);
+        if (S.n > 1)
+            for (int s = 0; s < S.n; s++) {
+                uint64_t held = 0;
+                pc_size(S.ctx[s], &held);
+                fprintf(stderr, "   slab %2d gpu %2d layers [%3d,%3d): %10lu points, binning %8.0f us, count %8.0f us\n", s,
+                        S.device[s], S.cut[s], S.cut[s + 1], (unsigned long)held, fin[s].ms[0] * 1e3, fin[s].ms[1] * 1e3);
+            }
     }
-    pc_destroy(ctx);
+    for (int s = 0; s < S.n; s++) pc_destroy(S.ctx[s]);
     return 0;
 }

@@ -86,12 +86,20 @@ def test_predicate_on_golden_pairs(psa, stages, torch_mod, oracle, golden_dir):
     for bv, cv in VARIANTS:
         total, _, _ = gpu_count(psa, stages, torch_mod, both, bin_v=bv, count_v=cv)
         assert total == want_total, (bv, cv)
-    idx = np.concatenate([np.arange(0, 64), np.arange(len(a) - 64, len(a))])
-    for i in idx:
-        c, _, _ = gpu_count(psa, stages, torch_mod, np.stack([a[i], b[i]]))
-        cell_adjacent = np.all(np.abs(np.floor((a[i] + 10.0) / 0.05) - np.floor((b[i] + 10.0) / 0.05)) <= 1)
-        if cell_adjacent:
-            assert c == int(within[i]), i
+    # every vector by itself: one launch per pair, restricted to the x layer of the lower point and its halo
+    # layer (all a pair can occupy), so that a launch costs microseconds
+    ca = np.floor((a.astype(np.float64) + 10.0) / 0.05).astype(np.int64)
+    cb = np.floor((b.astype(np.float64) + 10.0) / 0.05).astype(np.int64)
+    adjacent = np.all(np.abs(ca - cb) <= 1, axis=1)
+    assert adjacent.sum() > 4000
+    psa.set_variant("bin", 1)
+    for cv in (3, 0):
+        psa.set_variant("count", cv)
+        for i in np.nonzero(adjacent)[0]:
+            lo = int(min(ca[i, 0], cb[i, 0]))
+            t = dev(torch_mod, np.stack([a[i], b[i]]))
+            stages.count_pairs(t, lo, lo + 1)
+            assert stages.pairs() == int(within[i]), (i, cv)
 
 
 def test_golden_fixture_counts(psa, stages, torch_mod, golden_dir):
@@ -155,6 +163,42 @@ def test_edge_cases(psa, stages, torch_mod, oracle):
             for bv in (0, 1):
                 with pytest.raises(psa.PairCountError):
                     gpu_count(psa, stages, torch_mod, pts, bin_v=bv, count_v=4)
+    # the bad point LAST: the binning drops it, and the slot it would have taken at the end of its layer or
+    # pencil keeps what an earlier level left there (possibly the bad point itself); the pair test must
+    # neither follow such a slot into the table nor crash -- the call reports the domain error
+    for bad in (np.nan, np.inf, -np.inf, 3.0e38, -1.0e30):
+        for axis in (1, 2, 0):
+            for npts in (3, 64, 700):
+                pts = np.random.default_rng(npts).uniform(-9.9, 9.9, (npts, 3)).astype(np.float32)
+                pts[-1, axis] = bad
+                for cv in (0, 4, 3):
+                    with pytest.raises(psa.PairCountError):
+                        gpu_count(psa, stages, torch_mod, pts, bin_v=1, count_v=cv)
+
+
+def test_finish_reports_a_failure_again(psa, torch_mod, oracle):
+    """pc_finish after a failed pc_finish returns the same error, not a count of 0; so do pc_tests and
+    pc_phase_ms.  A good context next to it is unaffected."""
+    pts = np.array([[0.1, 0.2, 0.3], [0.1, 0.2, 0.3], [0.5, 11.0, 0.5]], np.float32)
+    pc = psa.PairCounter(device=0, expected_points=16)
+    pc.append(pts)
+    for _ in range(3):
+        with pytest.raises(psa.PairCountError) as e:
+            pc.finish()
+        assert e.value.code == -3
+    with pytest.raises(psa.PairCountError) as e:
+        pc.tests()
+    assert e.value.code == -3
+    with pytest.raises(psa.PairCountError):
+        pc.phase_ms()
+    with pytest.raises(psa.PairCountError) as e:
+        pc.append(pts[:1])
+    assert e.value.code == -5                      # closed for appends all the same
+    pc.close()
+    good = psa.PairCounter(device=0, expected_points=16)
+    good.append(pts[:2])
+    assert good.finish() == 1 and good.finish() == 1 and good.tests() == 1
+    good.close()
 
 
 def test_slab_shards_sum_to_whole(psa, stages, torch_mod, oracle):
