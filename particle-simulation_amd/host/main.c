@@ -373,8 +373,9 @@ int main(int argc, char **argv)
     }
     int64_t npairs = 0, tests = 0;
     float ms[2] = {0, 0};
+    for (int s = 0; s < S.n && S.n > 1; s++)          /* all of them, before any result is judged: no thread may */
+        if (pthread_join(fth[s], NULL) != 0) { perror("pthread_join"); exit(-1); }   /* still be inside HIP at exit */
     for (int s = 0; s < S.n; s++) {
-        if (S.n > 1 && pthread_join(fth[s], NULL) != 0) { perror("pthread_join"); exit(-1); }
         if (fin[s].rc != PC_OK) {
             fprintf(stderr, "pc_finish: %s\n", fin[s].msg);
             return -1;

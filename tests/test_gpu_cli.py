@@ -65,6 +65,52 @@ def test_main_on_binary_sidecar(ht, golden_dir, tmp_path):
     assert r.returncode == 0 and r.stdout == "0\n"
 
 
+def test_main_multi_gpu_slabs(ht, oracle, golden_dir, tmp_path):
+    """-g N: the parser threads route points to N slab contexts (here all on GPU 0, standing in for N GPUs),
+    the slabs are finished concurrently and summed: the golden counts, for text and binary input, for
+    equal and for explicit cuts, and with the timer's per-slab report."""
+    with open(os.path.join(golden_dir, "counts.json")) as f:
+        counts = json.load(f)
+    for name, info in counts.items():
+        for g, extra in (("2", {}), ("3", {"PAIRCOUNT_CUTS": "0,199,201,400"}), ("8", {})):
+            env = dict(os.environ, PAIRCOUNT_DEVICES=",".join("0" * int(g)), **extra)
+            r = subprocess.run([ht.MAIN_PATH, "-f", os.path.join(golden_dir, name), "-p", "5", "-g", g],
+                               capture_output=True, text=True, timeout=120, env=env)
+            assert r.returncode == 0, (name, g, r.stderr)
+            assert r.stdout == "%d\n" % info["count"], (name, g, r.stdout)
+    path = str(tmp_path / "b500k.xyz")
+    ht.generate_text(path, ht.BLOBS, 11, 500_000, 150_000)
+    pts = ht.generate(ht.BLOBS, 11, 500_000, 150_000)
+    want, tests = oracle.count_pairs(pts)
+    binp = str(tmp_path / "b500k.f32")
+    pts.tofile(binp)
+    for f in (path, binp):
+        env = dict(os.environ, PAIRCOUNT_GPUS="4", PAIRCOUNT_DEVICES="0,0,0,0", PAIRCOUNT_TIMER="1")
+        r = subprocess.run([ht.MAIN_PATH, "-f", f, "-p", "8"], capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 0, r.stderr
+        assert int(r.stdout) == want and want > 0
+        assert str(tests) in r.stderr and r.stderr.count("slab") == 4
+    # an out-of-domain point (only a binary file can hold one) is still an error, whichever slab it was routed to
+    for axis in range(3):
+        far = pts[:1000].copy()
+        far[500, axis] = 10.5
+        fp = str(tmp_path / ("far%d.f32" % axis))
+        far.tofile(fp)
+        r = subprocess.run([ht.MAIN_PATH, "-f", fp, "-g", "2"], capture_output=True, text=True, timeout=60,
+                           env=dict(os.environ, PAIRCOUNT_DEVICES="0,0"))
+        assert r.returncode == 255 and "domain" in r.stderr
+
+
+def test_main_error_statuses_of_the_reference(ht, tmp_path):
+    """No -f and an empty file fail as the reference does (open: EFAULT; mmap of zero bytes: EINVAL), status 255."""
+    r = subprocess.run([ht.MAIN_PATH], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 255 and r.stderr.startswith("open:")
+    empty = tmp_path / "empty.xyz"
+    empty.write_bytes(b"")
+    r = subprocess.run([ht.MAIN_PATH, "-f", str(empty)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 255 and r.stderr.startswith("mmap:")
+
+
 def test_main_reports_tokenizer_errors_like_the_reference(ht, tmp_path):
     bad = tmp_path / "bad.xyz"
     bad.write_text("1.000000 2.000000 3.000000\n12.500000 1.000000 1.000000\n" * 8)
