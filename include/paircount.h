@@ -150,6 +150,21 @@ int pc_count_pairs_device(const float *d_xyz, uint64_t n, int x_lo, int x_hi,
                           void *d_workspace, size_t workspace_bytes,
                           uint64_t *d_npairs, int32_t *d_status, void *stream);
 
+/* The same call for callers that cannot allocate device memory (code under HIP
+   graph capture, tight serving loops, harnesses that forbid hipMalloc): no
+   workspace argument -- the scratch memory lives in a fixed array inside the
+   library, one copy per GPU, held until the process ends (about 27 MB) -- and no
+   allocating call is made, by the library or through it.  n is limited to
+   PC_NOALLOC_MAX_POINTS; more is PC_ERR_ARG.  Every call on a GPU uses that GPU's
+   one array: calls that could overlap on one device (streams, host threads) race
+   and must be ordered by the caller; consecutive calls need no clean-up in
+   between.  The data's device must be current.  No counterpart in the reference
+   (its hash table is malloc'ed, hashmap.h:45-49,73-80). */
+#define PC_NOALLOC_MAX_POINTS 1048576ull
+int pc_count_pairs_noalloc(const float *d_xyz, uint64_t n, int x_lo, int x_hi,
+                           float *d_sorted_xyz, uint32_t *d_cell_start,
+                           uint64_t *d_npairs, int32_t *d_status, void *stream);
+
 /* Selects kernel variants (for A/B measurement and cross-checks); values are
    documented next to the kernels.  name: "bin" | "count", or "segments": the
    capacity of the pair test's list of heavy-pencil segments (default and

@@ -52,6 +52,7 @@ ABI = [
     ("pc_count_sorted_device", _i32, [_vp, _vp, _u64, _i32, _i32, _vp, _vp]),
     ("pc_count_tests_device", _i32, [_vp, _i32, _i32, _vp, _vp]),
     ("pc_count_pairs_device", _i32, [_vp, _u64, _i32, _i32, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    ("pc_count_pairs_noalloc", _i32, [_vp, _u64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     ("pc_set_variant", _i32, [_c.c_char_p, _i32]),
     ("pc_profile_enable", _i32, [_i32]),
     ("pc_profile_read", _i32, [_c.c_char_p, _sz]),

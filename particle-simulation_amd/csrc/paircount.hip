@@ -501,6 +501,53 @@ extern "C" int pc_count_pairs_device(const float *d_xyz, uint64_t n, int x_lo, i
     return pc_count_sorted_device(d_sorted_xyz, d_cell_start, n, x_lo, x_hi, d_npairs, stream);
 }
 
+// ------------------------------------------------- allocation-free entry point --
+// The binning workspace of pc_count_pairs_device (level-Y point array, y cells,
+// layer and pencil counters, cursors) in a fixed array inside the code object, so
+// that a caller who cannot allocate has nothing to bring but inputs and outputs.
+// Each device holds its own copy at its own address; host code reaches it only
+// through the pointer hipGetSymbolAddress returned for that device.
+#define PC_STATIC_MAX_POINTS PC_NOALLOC_MAX_POINTS
+static constexpr size_t PC_SCRATCH_BYTES = workspace_bytes_for(PC_STATIC_MAX_POINTS);
+static __device__ __align__(256) unsigned char scratch[PC_SCRATCH_BYTES];
+static unsigned char *g_scratch_ptr[64];
+
+static int scratch_of_current_device(unsigned char **out)
+{
+    int dev = 0;
+    PC_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return pc_fail(PC_ERR_ARG, "device ordinal %d not supported", dev);
+    pthread_mutex_lock(&g_queue_lock);
+    unsigned char *p = g_scratch_ptr[dev];
+    if (!p) {
+        hipError_t e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            pthread_mutex_unlock(&g_queue_lock);
+            return pc_fail(PC_ERR_HIP, "hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
+        }
+        g_scratch_ptr[dev] = p;
+    }
+    pthread_mutex_unlock(&g_queue_lock);
+    *out = p;
+    return PC_OK;
+}
+
+extern "C" int pc_count_pairs_noalloc(const float *d_xyz, uint64_t n, int x_lo, int x_hi,
+                                      float *d_sorted_xyz, uint32_t *d_cell_start,
+                                      uint64_t *d_npairs, int32_t *d_status, void *stream)
+{
+    if (n > PC_STATIC_MAX_POINTS)
+        return pc_fail(PC_ERR_ARG, "pc_count_pairs_noalloc: %llu points exceed the built-in workspace's %llu; use "
+                       "pc_count_pairs_device with a workspace of pc_workspace_bytes(n)",
+                       (unsigned long long)n, (unsigned long long)PC_STATIC_MAX_POINTS);
+    unsigned char *ws = nullptr;
+    int rc = scratch_of_current_device(&ws);
+    if (rc) return rc;
+    // the kernels clear the counters they need at the start of every call (bin_lds), the rest is overwritten
+    return pc_count_pairs_device(d_xyz, n, x_lo, x_hi, d_sorted_xyz, d_cell_start, ws, PC_SCRATCH_BYTES, d_npairs,
+                                 d_status, stream);
+}
+
 // --------------------------------------------------------------- streaming --
 struct pc_context {
     int device;
