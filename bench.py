@@ -56,6 +56,7 @@ def kernel_bytes(name, n, layers):
         "pc_c1_count_tiles": 12 * n + 4 * cells,
         "pc_c2_count_waves": 12 * n + 4 * cells,
         "pc_c3_count_groups": 12 * n + 4 * cells,
+        "pc_c5_count_merged": 12 * n + 4 * cells,
         "pc_l1_hist_x": 12 * n,
         "pc_l3_partition_x": 24 * n + 2 * n,                # points in and out, y cells out
         "pc_l4_hist_y": 2 * n,                              # y cells in

@@ -20,7 +20,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpaircount.so")
+LIB_PATH = os.environ.get("PAIRCOUNT_LIB") or os.path.join(HERE, "libpaircount.so")   # (override: A/B runs of library builds)
 
 PC_NBB = 403
 PC_NCELLS = PC_NBB ** 3

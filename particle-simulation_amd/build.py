@@ -23,7 +23,7 @@ ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CC = os.environ.get("CC", "gcc")
 
-HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall"]
+HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall"] + os.environ.get("PC_EXTRA_FLAGS", "").split()
 # x86-64-v3 (AVX2, BMI2, LZCNT): what the tokenizer's bit tricks compile to single instructions on; the
 # host CPUs of MI355X machines all have it.  (The reference builds with -O3 -march=native.)
 C_FLAGS = ["-O3", "-march=x86-64-v3", "-std=c11", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-pthread",
@@ -65,10 +65,15 @@ def build_hip(force=False):
         raise RuntimeError("fused f32 multiply-add in device code (breaks bit-exact parity):\n" + "\n".join(bad[:10]))
     # the pair-test kernel runs five waves per SIMD only up to 96 vector registers; one more costs a wave (3 % of its time)
     with open(asm) as f:
-        m = re.search(r"\.set _Z18pc_c3_count_groups\w*\.num_vgpr, (\d+)", f.read())
-    if m and int(m.group(1)) > 96:
-        print("warning: pc_c3_count_groups uses %s vector registers (> 96: four waves per SIMD instead of five)" % m.group(1),
-              file=sys.stderr)
+        text = f.read()
+    for kernel, limit in (("pc_c3_count_groups", 96), ("pc_c5_count_merged", 80)):
+        for m in re.finditer(r"\.set (_Z\d+%s\w*)\.num_vgpr, (\d+)" % kernel, text):
+            if int(m.group(2)) > limit:
+                print("warning: %s uses %s vector registers (> %d: one wave per SIMD fewer)" % (m.group(1), m.group(2), limit),
+                      file=sys.stderr)
+            spill = re.search(r"\.set %s\.private_seg_size, (\d+)" % re.escape(m.group(1)), text)
+            if spill and int(spill.group(1)) > 0:
+                print("warning: %s spills %s bytes per lane" % (m.group(1), spill.group(1)), file=sys.stderr)
     _run([HIPCC] + HIP_FLAGS + ["-shared", "-o", out, main_src, "-lpthread"])
     return out
 

@@ -16,6 +16,7 @@
 #include "pc_count_tile.h"
 #include "pc_count_wave.h"
 #include "pc_count_group.h"
+#include "pc_count_merge.h"
 #include "pc_generate.h"
 
 // ------------------------------------------------------------------ errors --
@@ -46,7 +47,8 @@ extern "C" const char *pc_version(void) { return "1.0 gfx950"; }
 // another thread launches is a defined read of the old or the new value, never a torn one.
 static std::atomic<int> g_variant_bin{1};     // 0 = atomic counting sort, 1 = LDS-staged three-level bucket sort
 // 0 = global memory, 1 = LDS-tiled strips, 2 = wave per pencil, 3 = candidate-parallel groups,
-// 4 = by density: 0 below 0.8 points per cell of the slab on average, else 3
+// 5 = merged single-run windows (variant 3's kernel for heavy pencils and what 5 defers),
+// 4 = by density: 0 below 0.8 points per cell of the slab on average, else 5
 static std::atomic<int> g_variant_count{4};
 static std::atomic<int> g_heavy{PC_G_HEAVY_CAP};    // capacity of the list of over-full cells' home-particle chunks (0: never listed)
 static std::atomic<int> g_segments{PC_G_SEG_CAP};  // capacity of the heavy-pencil segment list (0: pencils are never cut)
@@ -60,7 +62,7 @@ extern "C" int pc_set_variant(const char *name, int value)
         return PC_OK;
     }
     if (!strcmp(name, "count")) {
-        if (value < 0 || value > 4) return pc_fail(PC_ERR_ARG, "pc_set_variant: count variant %d unknown", value);
+        if (value < 0 || value > 5) return pc_fail(PC_ERR_ARG, "pc_set_variant: count variant %d unknown", value);
         g_variant_count = value;
         return PC_OK;
     }
@@ -417,13 +419,14 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
         // Sparse inputs: a window of 64 cells holds too few particles to pay for its bookkeeping, and the
         // thread-per-particle kernel wins (measured crossover at 55 M uniform points = 0.86 per cell).
         const uint64_t cells = (uint64_t)(x_hi < PC_NLAYERS ? x_hi - x_lo + 1 : x_hi - x_lo) * PC_NLAYERS * PC_NLAYERS;
-        variant = n * 5 < cells * 4 ? 0 : 3;
+        variant = n * 5 < cells * 4 ? 0 : 5;
     }
+    if (variant == 5 && n * 12 > 0xFFFFFFFFull) variant = 3;       // variant 5 addresses the sorted array by 32-bit byte offsets
     if (variant == 0) {
         uint32_t c_lo = (uint32_t)x_lo * PC_NBB2, c_hi = (uint32_t)x_hi * PC_NBB2;
         PC_LAUNCH("pc_c0_count_global", pc_c0_count_global, dim3(grid_for(n, 256, 4096)), dim3(256), (hipStream_t)stream, d_sorted_xyz, d_cell_start, c_lo, c_hi,
                            (unsigned long long *)d_npairs);
-    } else if (variant == 3) {
+    } else if (variant == 3 || variant == 5) {
         // persistent: one resident set of waves, never more waves than pencils;
         // the eight work counters are zeroed on the stream ahead of the launch
         unsigned int *queue = nullptr;
@@ -443,15 +446,35 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
             int per_cu = 0;
             hipDeviceProp_t prop;
             PC_HIP(hipGetDeviceProperties(&prop, dev));
-            PC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pc_c3_count_groups, PC_G_WAVES * 64, 0));
+            PC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pc_c3_count_groups<true>, PC_G_WAVES * 64, 0));
             resident = (per_cu > 0 ? per_cu : 16) * prop.multiProcessorCount;
             resident_on[dev] = resident;
         }
         const int want = resident, most = ((x_hi - x_lo) * PC_NLAYERS + PC_G_WAVES - 1) / PC_G_WAVES;
+        if (variant == 5) {
+            // the merged-window kernel takes every pencil the planner left whole; what it cannot process goes on the
+            // segment list, which the group kernel then works off together with the planned segments
+            static int resident5_on[64];
+            int r5 = resident5_on[dev];
+            if (!r5) {
+                int per_cu = 0;
+                hipDeviceProp_t prop;
+                PC_HIP(hipGetDeviceProperties(&prop, dev));
+                PC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pc_c5_count_merged, 64, 0));
+                r5 = (per_cu > 0 ? per_cu : 16) * prop.multiProcessorCount;
+                resident5_on[dev] = r5;
+            }
+            const int grid5 = ((r5 < most ? r5 : most) + 7) / 8 * 8;
+            PC_LAUNCH("pc_c5_count_merged", pc_c5_count_merged, dim3(grid5), dim3(64), (hipStream_t)stream,
+                      d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, (unsigned long long *)d_npairs);
+        }
         const int grid = ((want < most ? want : most) + 7) / 8 * 8;
-        PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
-                  d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap,
-                  (unsigned long long *)d_npairs);
+        if (variant == 5)
+            PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups<false>, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
+                      d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap, (unsigned long long *)d_npairs);
+        else
+            PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups<true>, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
+                      d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap, (unsigned long long *)d_npairs);
         // the home particles of over-full cells that the waves listed instead of processing (normally none:
         // the workgroups then return at once)
         PC_LAUNCH("pc_c3_heavy", pc_c3_heavy, dim3(resident >= 2048 ? 2048 : resident), dim3(PC_G_HEAVY_CHUNK), (hipStream_t)stream,

@@ -13,6 +13,48 @@
 #pragma once
 #include "pc_device.h"
 
+// Pairs of the home particle in sorted slot p with its candidates (the loop nest of
+// main.c:210-229 for one point): later slots of its cell, and the 13 forward cells.
+// Slots the binning left unwritten (it drops out-of-domain points and flags the status
+// word) still hold whatever the scratch use of the array put there: a point outside
+// the grid is never a home particle, and its key must not index the table.
+__device__ __forceinline__ uint32_t pc_count_one_home(const float *__restrict__ pts, const uint32_t *__restrict__ T, uint32_t p)
+{
+    struct pt3 { float x, y, z; };                 // one 12-byte load per point
+    const pt3 *P = reinterpret_cast<const pt3 *>(pts);
+    const pt3 me = P[p];
+    const float x = me.x, y = me.y, z = me.z;
+    const int ci = pc_cell_index(x), cj = pc_cell_index(y), ck = pc_cell_index(z);
+    if (!pc_in_grid(ci, cj, ck)) return 0;
+    const uint32_t c = pc_key(ci, cj, ck);
+    uint32_t cnt = 0;
+    // the five candidate ranges: same cell (later slots) with cell c+1 = slots (p, T[c+2]), then the
+    // three-cell runs of the four neighbour pencils; all ten table reads are issued before any is used
+    const uint32_t base[5] = {0u, 402u, 162005u, 162408u, 162811u};
+    uint32_t lo[5], hi[5];
+    lo[0] = p + 1;
+    hi[0] = T[c + 2];
+#pragma unroll
+    for (int r = 1; r < 5; r++) {
+        lo[r] = T[c + base[r]];
+        hi[r] = T[c + base[r] + 3];
+    }
+    // two candidates per turn, packed arithmetic (v_pk_add/mul_f32); the second one of an odd tail is masked
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f ax = {x, x}, ay = {y, y}, az = {z, z};
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        for (uint32_t q = lo[r]; q < hi[r]; q += 2) {
+            const pt3 v0 = P[q], v1 = P[min(q + 1, hi[r] - 1)];
+            const v2f cx = {v0.x, v1.x}, cy = {v0.y, v1.y}, cz = {v0.z, v1.z};
+            const v2f dx = ax - cx, dy = ay - cy, dz = az - cz;
+            const v2f sq = (dx * dx + dy * dy) + dz * dz;            // unfused: see the build flags
+            cnt += (sq.x <= 0.0025f) + ((sq.y <= 0.0025f) & (q + 1 < hi[r]));
+        }
+    }
+    return cnt;
+}
+
 __global__ void __launch_bounds__(256)
 pc_c0_count_global(const float *__restrict__ pts, const uint32_t *__restrict__ T,
                    uint32_t c_lo, uint32_t c_hi,   // home keys [c_lo, c_hi)
@@ -21,45 +63,8 @@ pc_c0_count_global(const float *__restrict__ pts, const uint32_t *__restrict__ T
     unsigned long long acc = 0;
     const uint32_t first = T[c_lo], last = T[c_hi];   // their slots in sorted order
     uint32_t stride = gridDim.x * blockDim.x;
-    for (uint64_t p64 = (uint64_t)first + blockIdx.x * blockDim.x + threadIdx.x; p64 < last; p64 += stride) {
-        uint32_t p = (uint32_t)p64;
-        struct pt3 { float x, y, z; };                 // one 12-byte load per point
-        const pt3 *P = reinterpret_cast<const pt3 *>(pts);
-        const pt3 me = P[p];
-        const float x = me.x, y = me.y, z = me.z;
-        // Slots the binning left unwritten (it drops out-of-domain points and flags the status word) still
-        // hold whatever the scratch use of the array put there: a point outside the grid is never a home
-        // particle, and its key must not index the table.
-        const int ci = pc_cell_index(x), cj = pc_cell_index(y), ck = pc_cell_index(z);
-        if (!pc_in_grid(ci, cj, ck)) continue;
-        uint32_t c = pc_key(ci, cj, ck);
-        uint32_t cnt = 0;
-        // the five candidate ranges: same cell (later slots) with cell c+1 = slots (p, T[c+2]), then the
-        // three-cell runs of the four neighbour pencils; all ten table reads are issued before any is used
-        const uint32_t base[5] = {0u, 402u, 162005u, 162408u, 162811u};
-        uint32_t lo[5], hi[5];
-        lo[0] = p + 1;
-        hi[0] = T[c + 2];
-#pragma unroll
-        for (int r = 1; r < 5; r++) {
-            lo[r] = T[c + base[r]];
-            hi[r] = T[c + base[r] + 3];
-        }
-        // two candidates per turn, packed arithmetic (v_pk_add/mul_f32); the second one of an odd tail is masked
-        typedef float v2f __attribute__((ext_vector_type(2)));
-        const v2f ax = {x, x}, ay = {y, y}, az = {z, z};
-#pragma unroll
-        for (int r = 0; r < 5; r++) {
-            for (uint32_t q = lo[r]; q < hi[r]; q += 2) {
-                const pt3 v0 = P[q], v1 = P[min(q + 1, hi[r] - 1)];
-                const v2f cx = {v0.x, v1.x}, cy = {v0.y, v1.y}, cz = {v0.z, v1.z};
-                const v2f dx = ax - cx, dy = ay - cy, dz = az - cz;
-                const v2f sq = (dx * dx + dy * dy) + dz * dz;            // unfused: see the build flags
-                cnt += (sq.x <= 0.0025f) + ((sq.y <= 0.0025f) & (q + 1 < hi[r]));
-            }
-        }
-        acc += cnt;
-    }
+    for (uint64_t p64 = (uint64_t)first + blockIdx.x * blockDim.x + threadIdx.x; p64 < last; p64 += stride)
+        acc += pc_count_one_home(pts, T, (uint32_t)p64);
     pc_block_add_u64<4>(acc, out);
 }
 

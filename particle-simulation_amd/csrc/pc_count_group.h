@@ -365,6 +365,8 @@ pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__r
     reinterpret_cast<unsigned char *>(work + PC_G_FLAGS)[pencil] = planned;
 }
 
+// WHOLE_PENCILS false: the whole pencils have been counted by another kernel, only the listed segments are left
+template <bool WHOLE_PENCILS>
 __global__ void __launch_bounds__(PC_G_WAVES * 64, 4)   // registers and LDS admit 5 waves per SIMD
 pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T, int x_lo, int x_hi,
                    unsigned int *__restrict__ queue, uint32_t seg_cap, uint32_t heavy_cap,
@@ -391,10 +393,14 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
     int g = blockIdx.x & 7, bands_done = 0;
     const int band_pencils = (x_hi - x_lo) * PC_G_BAND;
     const unsigned char *planned = reinterpret_cast<const unsigned char *>(queue + PC_G_FLAGS);
-    bool segment_phase = false;
+    bool segment_phase = !WHOLE_PENCILS;
     int n_segments = 0;
     int m = 0;
-    if (lane == 0) m = (int)atomicAdd(queue + g * PC_G_QUEUE_STRIDE, 1u);
+    if (segment_phase) {
+        n_segments = (int)min(__builtin_amdgcn_readfirstlane(queue[PC_G_SEG_COUNT]), seg_cap);
+        if (n_segments == 0) return;                       // (nothing was added to the sum: no atomic either)
+        if (lane == 0) m = (int)atomicAdd(queue + PC_G_SEG_DRAW, 1u);
+    } else if (lane == 0) m = (int)atomicAdd(queue + g * PC_G_QUEUE_STRIDE, 1u);
     m = __builtin_amdgcn_readfirstlane(m);
     for (;;) {
         int layer, j, z_begin = 0, z_end = PC_NLAYERS, m_next = 0;

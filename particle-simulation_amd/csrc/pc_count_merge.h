@@ -1,0 +1,309 @@
+// Pair test, variant 5 ("merge"): the form for moderately filled grids (about
+// half a point to a few tens of points per cell), where a window's bookkeeping,
+// not the distance arithmetic, decides the time.
+//
+// Replaces counter_thread/compare/count_chunk/dist2 (reference main.c:85-91,
+// 161-234).  One wavefront owns one home pencil (i,j) and walks it in windows of
+// up to 62 home cells.  ALL FIVE pencils a home particle meets -- its own ("row
+// 0") and (i,j+1) (i+1,j-1) (i+1,j) (i+1,j+1) ("rows 1-4": the offsets of
+// main.c:195-209) -- are copied into ONE array in LDS, ordered in blocks
+//
+//     S_k = [ row 0, cell k | rows 1-4, cell k-1 ]        (padded to an even length)
+//
+// so that everything a home particle in slot q of S_k has to be tested against
+// lies in the single run (q, end of S_{k+2}): the later points of its own cell,
+// rows 1-4 of cell k-1, row 0 of cell k+1, rows 1-4 of cell k, [row 0 of cell k+2],
+// rows 1-4 of cell k+1.  The bracketed part is not among the 13 neighbour cells, and
+// neither is anything a lane reads past the end of a run (blocks S_{k+3}...): such
+// points lie two or more cells away along z and can never pass the predicate --
+//
+//   cells k and k+2 on one axis:  the reference's index (main.c:134-136) puts the
+//   points at least 0.05 - 9e-15 apart on that axis (binary64 rounding of the two
+//   quotients, at most 803 ulps of 0.05); their binary32 difference is then at least
+//   0.05f = 0.0500000007..., its rounded square at least 0.00250000017... > 0.0025f,
+//   and adding the other two (non-negative) squares with round-to-nearest cannot
+//   bring the sum below that --
+//
+// so they may be tested freely: no range masks, only the loop's exit condition
+// looks at the run's end.  A run starts on the even slot at or after q + 1... when
+// that pair holds q itself (q even) the home particle matches itself once, which
+// is subtracted by counting the even home slots.  Dead lanes and the slots after
+// the last block hold NaN coordinates and never match.
+//
+// The copy is a gather through LDS-DMA loads driven by a list of byte offsets into
+// the sorted array (kept where the z coordinates will land, consumed just before).
+// A group of G lanes takes one home particle, lane j the pairs j, j+G, ... of its
+// run; G follows the mean run length of the window.
+//
+// Windows this scheme does not suit (a cell with its neighbourhood exceeds the LDS
+// arrays, or runs of more than about 130 points) are not processed here: the rest
+// of the pencil goes on the segment list of variant 3's kernel, which runs after
+// this one for the planned and the deferred segments only; if the list is full the
+// wave counts the rest of the pencil itself, one lane per home particle, from global
+// memory.  pc_set_variant("count", 5); chosen by density in the default variant 4.
+#pragma once
+#include "pc_count_global.h"
+#include "pc_count_group.h"
+
+#ifndef PC_M_CAP
+#define PC_M_CAP 448                    // slots of a window's blocks (even)
+#endif
+#define PC_M_CAPH 160                   // home particles of a window
+#define PC_M_SLACK 80                   // never-matching slots behind the last block: a lane's first pass reads at most 66 past it
+#define PC_M_LEN (PC_M_CAP + PC_M_SLACK)
+#define PC_M_MAX_G 16
+
+struct alignas(16) pc_merge_lds {
+    float x[PC_M_LEN], y[PC_M_LEN];
+    union {
+        float z[PC_M_LEN];
+        uint32_t src[PC_M_LEN];         // byte offset of every slot's point in the sorted array, until the copy is issued
+    };
+    uint32_t home[PC_M_CAPH + 64 / 2];  // per home particle: slot | end of its run << 16; then one step's worth of dead entries
+};
+
+template <int BYTES>
+__device__ __forceinline__ pc_v2f pc_m_pair(uint32_t lds_byte_addr)
+{
+    pc_v2f v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(lds_byte_addr), "n"(BYTES));
+    return v;
+}
+
+// pairs c = 0..NP-1 of a lane: candidates 2*G*c and 2*G*c + 1 past the lane's first, from the three coordinate arrays;
+// all requests go out before the first value is used
+template <int G, int... C>
+__device__ __forceinline__ void pc_m_request(uint32_t ap, pc_v2f *x, pc_v2f *y, pc_v2f *z, std::integer_sequence<int, C...>)
+{
+    ((x[C] = pc_m_pair<8 * G * C>(ap), y[C] = pc_m_pair<4 * PC_M_LEN + 8 * G * C>(ap),
+      z[C] = pc_m_pair<8 * PC_M_LEN + 8 * G * C>(ap)), ...);
+}
+
+// NP pairs of every lane against its group's home particle: hits of the whole wave
+template <int G, int NP>
+__device__ __forceinline__ uint32_t pc_m_test(uint32_t ap, pc_v2f ax, pc_v2f ay, pc_v2f az)
+{
+    pc_v2f x[NP], y[NP], z[NP], sq[NP];
+    pc_m_request<G>(ap, x, y, z, std::make_integer_sequence<int, NP>());
+#pragma unroll
+    for (int c = 0; c < NP; c++) {
+        pc_lds_pairs_arrived(x[c], y[c], z[c]);
+        // (dx*dx + dy*dy) + dz*dz, each step rounded separately (no contraction: see build flags)
+        const pc_v2f dx = ax - x[c], dy = ay - y[c], dz = az - z[c];
+        sq[c] = (dx * dx + dy * dy) + dz * dz;
+    }
+    uint32_t hits = 0;
+#pragma unroll
+    for (int c = 0; c < NP; c++)
+        hits += __popcll(__builtin_amdgcn_ballot_w64(sq[c].x <= 0.0025f)) + __popcll(__builtin_amdgcn_ballot_w64(sq[c].y <= 0.0025f));
+    return hits;
+}
+
+// All nh home particles of the staged window, 64/G per step.
+template <int G>
+__device__ __forceinline__ uint32_t pc_m_steps(const pc_merge_lds &L, uint32_t nh, uint32_t tot, int lane)
+{
+    constexpr int H = 64 / G;
+    constexpr int NP0 = G <= 8 ? 4 : 2;                 // pairs per lane before the run's end is looked at
+    uint32_t hits = 0, selfs = 0;
+    asm volatile("" : "+v"(lane));                      // per-lane constants are recomputed per window, not kept in registers
+    const uint32_t j = lane & (G - 1), grp = lane / G;
+    nh = __builtin_amdgcn_readfirstlane(nh);
+    tot = __builtin_amdgcn_readfirstlane(tot);
+    const uint32_t x_lds = pc_lds_addr(L.x);
+    for (uint32_t base = 0; base < nh; base += H) {
+        const uint32_t e = L.home[base + grp];           // past nh: dead entries (odd NaN slot, empty run)
+        const uint32_t q = e & 0xFFFFu;
+        const float hx = L.x[q], hy = L.y[q], hz = L.z[q];
+        const pc_v2f ax = {hx, hx}, ay = {hy, hy}, az = {hz, hz};
+        uint32_t p = ((q + 1) >> 1) + j;                 // the lane's first pair
+        int rem = (int)(e >> 16) - (int)(2 * p);          // slots from there to the end of the run
+        // lane 0 of a group with an even home slot has the home particle itself in its first pair
+        selfs += __popcll(__builtin_amdgcn_ballot_w64(((q & 1u) | j) == 0u));
+        uint32_t ap = x_lds + 8 * p;
+        hits += pc_m_test<G, NP0>(ap, ax, ay, az);
+        rem -= 2 * G * NP0;
+        p += G * NP0;
+        while (__builtin_amdgcn_ballot_w64(rem > 0) != 0) {
+            p = min(p, tot >> 1);                         // finished lanes wait on the never-matching slots
+            hits += pc_m_test<G, 1>(x_lds + 8 * p, ax, ay, az);
+            rem -= 2 * G;
+            p += G;
+        }
+    }
+    return hits - selfs;    // wave-uniform
+}
+
+// The rest [z0, 400) of a pencil that this kernel does not process: onto the segment
+// list of pc_c3_count_groups if there is room, else counted here and now.
+__device__ __forceinline__ unsigned long long pc_m_defer(const float *__restrict__ pts, const uint32_t *__restrict__ T,
+                                                         unsigned int *__restrict__ queue, uint32_t seg_cap,
+                                                         uint32_t pencil, int z0, uint32_t home_hi, int lane)
+{
+    uint32_t at = 0xFFFFFFFFu;
+    if (lane == 0 && seg_cap != 0) {
+        at = atomicAdd(queue + PC_G_SEG_COUNT, 1u);
+        if (at < seg_cap) {
+            queue[PC_G_SEGS + 2 * at] = pencil + 1;
+            queue[PC_G_SEGS + 2 * at + 1] = (uint32_t)z0 | ((uint32_t)PC_NLAYERS << 16);
+        }
+    }
+    at = __builtin_amdgcn_readfirstlane(at);
+    if (at < seg_cap) return 0;
+    unsigned long long acc = 0;
+    for (uint64_t p = (uint64_t)T[(uint64_t)pencil * PC_NBB + z0] + lane; p < home_hi; p += 64)
+        acc += pc_count_one_home(pts, T, (uint32_t)p);
+    return acc;
+}
+
+__global__ void __launch_bounds__(64, 6)
+pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T, int x_lo, int x_hi,
+                   unsigned int *__restrict__ queue, uint32_t seg_cap, unsigned long long *__restrict__ out)
+{
+    __shared__ pc_merge_lds L;
+    const int lane = threadIdx.x;
+    unsigned long long acc = 0;          // per-lane partial (lane 0 also carries the wave-uniform hit counts)
+
+    // Persistent waves, one work counter per XCD group (workgroups with equal
+    // blockIdx%8 share an XCD): the group walks the band of 50 pencils
+    // y = g*50 .. g*50+49 layer by layer, so neighbouring pencils are in flight
+    // together and stay in that XCD's L2; a wave whose band is used up moves on to
+    // the next group's band and leaves once all eight counters are past the end.
+    int g = blockIdx.x & 7, bands_done = 0;
+    const int band_pencils = (x_hi - x_lo) * PC_G_BAND;
+    const unsigned char *planned = reinterpret_cast<const unsigned char *>(queue + PC_G_FLAGS);
+    int m = 0;
+    if (lane == 0) m = (int)atomicAdd(queue + g * PC_G_QUEUE_STRIDE, 1u);
+    m = __builtin_amdgcn_readfirstlane(m);
+    for (;;) {
+        while (m >= band_pencils && ++bands_done < 8) {
+            g = (g + 1) & 7;
+            if (lane == 0) m = (int)atomicAdd(queue + g * PC_G_QUEUE_STRIDE, 1u);
+            m = __builtin_amdgcn_readfirstlane(m);
+        }
+        if (m >= band_pencils) break;
+        int m_next = 0;
+        if (lane == 0) m_next = (int)atomicAdd(queue + g * PC_G_QUEUE_STRIDE, 1u);   // (its latency hides behind the pencil)
+        const int layer = x_lo + m / PC_G_BAND, j = g * PC_G_BAND + m % PC_G_BAND;
+        const uint32_t pencil = (uint32_t)layer * PC_NBB + j;
+        const uint32_t skip = planned[pencil];            // cut into segments by the planning kernel: variant 3's kernel takes it
+
+        // table bases of the five rows; a row outside the occupied grid is empty (its base only has to be readable at -1)
+        const int ri[5] = {layer, layer, layer + 1, layer + 1, layer + 1};
+        const int rj[5] = {j, j + 1, j - 1, j, j + 1};
+        uint32_t tb[5];
+        bool valid[5];
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            valid[r] = ri[r] < PC_NLAYERS && rj[r] >= 0 && rj[r] < PC_NLAYERS;
+            tb[r] = valid[r] ? ((uint32_t)ri[r] * PC_NBB + rj[r]) * PC_NBB : tb[0] + PC_NBB;
+        }
+        const uint32_t home_lo = T[tb[0]], home_hi = T[tb[0] + PC_NLAYERS];
+        int z0 = 0;
+        uint32_t done = skip ? home_hi : home_lo;          // first home slot not yet processed
+        // Lane t of a window starting at home cell z0 owns block S_{z0+t}: row 0 at cell z0+t, rows 1-4 at
+        // cell z0+t-1.  (Cell -1 of a row reads the last, always empty, padding cell of the pencil before it;
+        // cells past 402 are clamped to 402: empty as well.)  a0/a1 = start of that cell and of the next one.
+        uint32_t a0[5], a1[5];
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const int c = min(lane - (r ? 1 : 0), PC_NBB - 1);
+            const uint32_t *e = T + ((int64_t)tb[r] + c);
+            a0[r] = e[0];
+            a1[r] = e[1];
+        }
+        while (done != home_hi && z0 < PC_NLAYERS) {
+            uint32_t s[5], n[5];
+#pragma unroll
+            for (int r = 0; r < 5; r++) {
+                s[r] = a0[r];
+                n[r] = valid[r] ? a1[r] - a0[r] : 0u;
+            }
+            const uint32_t n_blk = n[0] + n[1] + n[2] + n[3] + n[4];
+            const uint32_t bs = (n_blk + 1) & ~1u;          // blocks start on even slots
+            const uint32_t cum = pc_wave_incl_scan(bs), cumh = pc_wave_incl_scan(n[0]);
+            // blocks that fit (a prefix); the last two only supply candidates
+            const int nblk = __popcll(__builtin_amdgcn_ballot_w64(cum <= PC_M_CAP && cumh <= PC_M_CAPH));
+            const bool fits = nblk >= 3;
+            const int w = nblk - 2;                         // home cells z0 .. z0+w-1
+            const int z_next = z0 + w;
+            if (fits) {   // request the next window's table entries now: they arrive while this one is processed
+#pragma unroll
+                for (int r = 0; r < 5; r++) {
+                    const int c = min(z_next + lane - (r ? 1 : 0), PC_NBB - 1);
+                    const uint32_t *e = T + ((int64_t)tb[r] + c);
+                    a0[r] = e[0];
+                    a1[r] = e[1];
+                }
+            }
+            uint32_t tot = 0, nh = 0;
+            if (fits) {
+                tot = pc_lane_value(cum, nblk - 1);
+                nh = pc_lane_value(cumh, w - 1);
+            }
+            // run lengths: three blocks on average; beyond about 130 slots variant 3's kernel does better
+            const bool suited = fits && 3u * tot <= 130u * (uint32_t)nblk;
+            if (!suited) {
+                const unsigned long long slow = pc_m_defer(pts, T, queue, seg_cap, pencil, z0, home_hi, lane);
+                acc += slow;
+                break;
+            }
+            done = pc_lane_value(s[0], w);                 // start of the first home cell of the next window
+            if (nh != 0) {
+                if (lane >= nblk) { n[0] = 0; n[1] = 0; n[2] = 0; n[3] = 0; n[4] = 0; }
+                const uint32_t ex = cum - bs, exh = cumh - n[0];
+                // end of S_{t+2}: the inclusive sum two lanes up
+                const uint32_t end2 = pc_from_lane_above(pc_from_lane_above(cum));
+                // ---- stage 1, lane = block: byte offsets of the block's points, row after row; home entries
+                {
+                    const uint32_t nhome = lane < w ? n[0] : 0u;
+                    const uint32_t ent = ex | (end2 << 16);
+                    for (uint32_t v = 0; __builtin_amdgcn_ballot_w64(v < n[0]) != 0; v++) {
+                        if (v < n[0]) L.src[ex + v] = 12u * (s[0] + v);
+                        if (v < nhome) L.home[exh + v] = ent + v;
+                    }
+                    uint32_t o = ex + n[0];
+#pragma unroll
+                    for (int r = 1; r < 5; r++) {
+                        for (uint32_t v = 0; __builtin_amdgcn_ballot_w64(v < n[r]) != 0; v++)
+                            if (v < n[r]) L.src[o + v] = 12u * (s[r] + v);
+                        o += n[r];
+                    }
+                    if (n_blk & 1u & (lane < nblk)) L.src[o] = 12u * home_lo;      // the pad slot copies any valid point ...
+                    // one step's worth of dead home entries: an odd slot in the never-matching tail, an empty run
+                    if (lane < 32) L.home[nh + lane] = (tot + 1) | ((tot + 1) << 16);
+                }
+                pc_wave_lds_sync();
+                // ---- stage 2, lane = slot: gather the points through the list, straight into LDS (no registers)
+                const char *bytes = reinterpret_cast<const char *>(pts);
+                for (uint32_t q0 = 0; q0 < tot; q0 += 64) {
+                    const uint32_t q = q0 + lane;
+                    const uint32_t off = q < tot ? L.src[q] : 12u * home_lo;
+                    pc_dma_point(reinterpret_cast<const float *>(bytes + off), L.x + q0, L.y + q0, L.z + q0);
+                }
+                pc_dma_wait();
+                const float never = __builtin_nanf("");
+                if ((n_blk & 1u) && lane < nblk) L.x[ex + n_blk] = never;           // ... and then never matches
+                L.x[tot + lane] = never;
+                if (lane < PC_M_SLACK - 64) L.x[tot + 64 + lane] = never;
+                pc_wave_lds_sync();
+                // ---- the tests: group width from the mean run length (three blocks)
+                const uint32_t m3 = 3u * tot, blocks = (uint32_t)nblk;
+                uint32_t hits;
+#ifdef PC_M_EXP_NOTEST
+                hits = 0;
+                if (m3 == 0xFFFFFFFFu)
+#endif
+                if (m3 <= 12u * blocks) hits = pc_m_steps<2>(L, nh, tot, lane);
+                else if (m3 <= 28u * blocks) hits = pc_m_steps<4>(L, nh, tot, lane);
+                else if (m3 <= 60u * blocks) hits = pc_m_steps<8>(L, nh, tot, lane);
+                else hits = pc_m_steps<16>(L, nh, tot, lane);
+                if (lane == 0) acc += hits;
+                pc_wave_lds_sync();
+            }
+            z0 = z_next;
+        }
+        m = __builtin_amdgcn_readfirstlane(m_next);
+    }
+    pc_block_add_u64<1>(acc, out);
+}

@@ -37,7 +37,7 @@ def dev(torch_mod, a):
     return torch_mod.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to("cuda:0")
 
 
-VARIANTS = [(1, 4), (1, 3), (0, 0), (1, 1), (0, 2)]      # (binning variant, pair-test variant; 4 = chosen by density)
+VARIANTS = [(1, 4), (1, 5), (1, 3), (0, 0), (1, 1), (0, 2)]      # (binning variant, pair-test variant; 4 = chosen by density)
 
 
 def gpu_count(psa, stages, torch_mod, xyz, x_lo=0, x_hi=400, bin_v=1, count_v=4):
@@ -93,7 +93,7 @@ def test_predicate_on_golden_pairs(psa, stages, torch_mod, oracle, golden_dir):
     adjacent = np.all(np.abs(ca - cb) <= 1, axis=1)
     assert adjacent.sum() > 4000
     psa.set_variant("bin", 1)
-    for cv in (3, 0):
+    for cv in (5, 3, 0):
         psa.set_variant("count", cv)
         for i in np.nonzero(adjacent)[0]:
             lo = int(min(ca[i, 0], cb[i, 0]))
@@ -412,8 +412,9 @@ def test_heavy_cell_list_overflow(psa, stages, torch_mod, oracle):
     try:
         for cap in (65536, 0, 1, 9, 12, 21, 22, 30):
             psa.set_variant("heavy", cap)
-            got, tests, _ = gpu_count(psa, stages, torch_mod, xyz, bin_v=1, count_v=3)
-            assert got == want and tests == want_tests, cap
+            for cv in (3, 5):
+                got, tests, _ = gpu_count(psa, stages, torch_mod, xyz, bin_v=1, count_v=cv)
+                assert got == want and tests == want_tests, (cap, cv)
     finally:
         psa.set_variant("heavy", 65536)
 
@@ -457,9 +458,10 @@ def test_segment_list_overflow(psa, stages, torch_mod, oracle):
     try:
         for cap in (262144, 0, 1, 3, 7, 16, 40, 1000):
             psa.set_variant("segments", cap)
-            got, tests, _ = gpu_count(psa, stages, torch_mod, xyz, count_v=3)      # (by density this input would take variant 0)
-            assert got == want, cap
-            assert tests == want_tests
+            for cv in (3, 5):      # (by density this input would take variant 0; 5 also puts what it defers on the list)
+                got, tests, _ = gpu_count(psa, stages, torch_mod, xyz, count_v=cv)
+                assert got == want, (cap, cv)
+                assert tests == want_tests
         with pytest.raises(psa.PairCountError):
             psa.set_variant("segments", 262145)
     finally:
