@@ -1,6 +1,6 @@
 // Pair test, variant 5 ("merge"): the form for moderately filled grids (about
-// half a point to a few tens of points per cell), where a window's bookkeeping,
-// not the distance arithmetic, decides the time.
+// half a point to a few tens of points per cell), where a window's bookkeeping
+// and the copy into LDS, not the distance arithmetic, decide the time.
 //
 // Replaces counter_thread/compare/count_chunk/dist2 (reference main.c:85-91,
 // 161-234).  One wavefront owns one home pencil (i,j) and walks it in windows of
@@ -8,7 +8,7 @@
 // 0") and (i,j+1) (i+1,j-1) (i+1,j) (i+1,j+1) ("rows 1-4": the offsets of
 // main.c:195-209) -- are copied into ONE array in LDS, ordered in blocks
 //
-//     S_k = [ row 0, cell k | rows 1-4, cell k-1 ]        (padded to an even length)
+//     S_k = [ row 0, cell k | rows 1-4, cell k-1 ]
 //
 // so that everything a home particle in slot q of S_k has to be tested against
 // lies in the single run (q, end of S_{k+2}): the later points of its own cell,
@@ -25,18 +25,18 @@
 //   bring the sum below that --
 //
 // so they may be tested freely: no range masks, only the loop's exit condition
-// looks at the run's end.  A run starts on the even slot at or after q + 1... when
-// that pair holds q itself (q even) the home particle matches itself once, which
-// is subtracted by counting the even home slots.  Dead lanes and the slots after
-// the last block hold NaN coordinates and never match.
+// looks at the run's end.  Dead lanes and the slots after the last block hold NaN
+// coordinates and never match.
 //
-// The copy is a gather through LDS-DMA loads driven by a list of byte offsets into
-// the sorted array (kept where the z coordinates will land, consumed just before).
-// A group of G lanes takes one home particle, lane j the pairs j, j+G, ... of its
-// run; G follows the mean run length of the window.
+// A slot is 16 bytes (x, y, z, one unused word): the layout a 12-byte LDS-DMA load
+// writes, so the copy is ONE gather instruction per 64 points, driven by a list of
+// byte offsets into the sorted array, and a candidate is ONE 16-byte LDS read,
+// consecutive lanes on consecutive slots (no bank conflicts).  A group of G lanes
+// takes one home particle, lane j the slots j, j+G, ... of its run; G follows the
+// mean run length of the window.
 //
 // Windows this scheme does not suit (a cell with its neighbourhood exceeds the LDS
-// arrays, or runs of more than about 130 points) are not processed here: the rest
+// array, or runs of more than about 130 points) are not processed here: the rest
 // of the pencil goes on the segment list of variant 3's kernel, which runs after
 // this one for the planned and the deferred segments only; if the list is full the
 // wave counts the rest of the pencil itself, one lane per home particle, from global
@@ -46,56 +46,72 @@
 #include "pc_count_group.h"
 
 #ifndef PC_M_CAP
-#define PC_M_CAP 448                    // slots of a window's blocks (even)
+#define PC_M_CAP 384                    // slots of a window's blocks (even)
 #endif
 #define PC_M_CAPH 160                   // home particles of a window
-#define PC_M_SLACK 80                   // never-matching slots behind the last block: a lane's first pass reads at most 66 past it
+#define PC_M_SLACK 80                   // never-matching slots behind the last block: a lane's first pass reads at most 65 past it
 #define PC_M_LEN (PC_M_CAP + PC_M_SLACK)
 #define PC_M_MAX_G 16
 
+// A window in LDS: one 16-byte slot per point -- the layout a 12-byte LDS-DMA load writes (lane t's three
+// words land at byte 16 t of the destination, the fourth is left alone).
+// The gather list -- one byte offset into the sorted array per slot -- lies over the start of the same array:
+// the copy runs from the last chunk of 64 slots to the first, so a chunk's 1024 bytes never reach the
+// 256-byte list pieces of the chunks still to come.
+typedef float pc_v4f __attribute__((ext_vector_type(4)));
+
 struct alignas(16) pc_merge_lds {
-    float x[PC_M_LEN], y[PC_M_LEN];
     union {
-        float z[PC_M_LEN];
-        uint32_t src[PC_M_LEN];         // byte offset of every slot's point in the sorted array, until the copy is issued
+        pc_v4f pt[PC_M_LEN];
+        uint32_t src[PC_M_LEN];
     };
     uint32_t home[PC_M_CAPH + 64 / 2];  // per home particle: slot | end of its run << 16; then one step's worth of dead entries
 };
 
-template <int BYTES>
-__device__ __forceinline__ pc_v2f pc_m_pair(uint32_t lds_byte_addr)
+// one point (12 bytes) per lane from global memory straight into LDS: lane t's x,y,z land in lds_chunk[t]
+__device__ __forceinline__ void pc_m_dma_point(const void *g, pc_v4f *lds_chunk)
 {
-    pc_v2f v;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(lds_byte_addr), "n"(BYTES));
+    __builtin_amdgcn_global_load_lds((pc_glb_void *)g, (pc_lds_void *)lds_chunk, 12, 0, 0);
+}
+
+template <int BYTES>
+__device__ __forceinline__ pc_v4f pc_m_slot(uint32_t lds_byte_addr)
+{
+    pc_v4f v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_byte_addr), "n"(BYTES));
     return v;
 }
-
-// pairs c = 0..NP-1 of a lane: candidates 2*G*c and 2*G*c + 1 past the lane's first, from the three coordinate arrays;
-// all requests go out before the first value is used
-template <int G, int... C>
-__device__ __forceinline__ void pc_m_request(uint32_t ap, pc_v2f *x, pc_v2f *y, pc_v2f *z, std::integer_sequence<int, C...>)
+__device__ __forceinline__ void pc_m_arrived(pc_v4f &a)
 {
-    ((x[C] = pc_m_pair<8 * G * C>(ap), y[C] = pc_m_pair<4 * PC_M_LEN + 8 * G * C>(ap),
-      z[C] = pc_m_pair<8 * PC_M_LEN + 8 * G * C>(ap)), ...);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a) : : "memory");
 }
 
-// NP pairs of every lane against its group's home particle: hits of the whole wave
-template <int G, int NP>
-__device__ __forceinline__ uint32_t pc_m_test(uint32_t ap, pc_v2f ax, pc_v2f ay, pc_v2f az)
+// slots c = 0..NS-1 of a lane: G*c past the lane's first; all requests go out before the first value is used
+template <int G, int... C>
+__device__ __forceinline__ void pc_m_request(uint32_t ap, pc_v4f *a, std::integer_sequence<int, C...>)
 {
-    pc_v2f x[NP], y[NP], z[NP], sq[NP];
-    pc_m_request<G>(ap, x, y, z, std::make_integer_sequence<int, NP>());
+    ((a[C] = pc_m_slot<16 * G * C>(ap)), ...);
+}
+
+// NS slots of every lane against its group's home particle: hits of the whole wave
+template <int G, int NS>
+__device__ __forceinline__ uint32_t pc_m_test(uint32_t ap, pc_v2f hxy, float hz)
+{
+    pc_v4f a[NS];
+    float sq[NS];
+    pc_m_request<G>(ap, a, std::make_integer_sequence<int, NS>());
 #pragma unroll
-    for (int c = 0; c < NP; c++) {
-        pc_lds_pairs_arrived(x[c], y[c], z[c]);
+    for (int k = 0; k < NS; k++) {
+        pc_m_arrived(a[k]);
         // (dx*dx + dy*dy) + dz*dz, each step rounded separately (no contraction: see build flags)
-        const pc_v2f dx = ax - x[c], dy = ay - y[c], dz = az - z[c];
-        sq[c] = (dx * dx + dy * dy) + dz * dz;
+        const pc_v2f d = hxy - pc_v2f{a[k].x, a[k].y};
+        const float e = hz - a[k].z;
+        const pc_v2f dd = d * d;
+        sq[k] = (dd.x + dd.y) + e * e;
     }
     uint32_t hits = 0;
 #pragma unroll
-    for (int c = 0; c < NP; c++)
-        hits += __popcll(__builtin_amdgcn_ballot_w64(sq[c].x <= 0.0025f)) + __popcll(__builtin_amdgcn_ballot_w64(sq[c].y <= 0.0025f));
+    for (int k = 0; k < NS; k++) hits += __popcll(__builtin_amdgcn_ballot_w64(sq[k] <= 0.0025f));
     return hits;
 }
 
@@ -104,34 +120,32 @@ template <int G>
 __device__ __forceinline__ uint32_t pc_m_steps(const pc_merge_lds &L, uint32_t nh, uint32_t tot, int lane)
 {
     constexpr int H = 64 / G;
-    constexpr int NP0 = G <= 8 ? 4 : 2;                 // pairs per lane before the run's end is looked at
-    uint32_t hits = 0, selfs = 0;
+    constexpr int NS0 = G <= 8 ? 8 : 4;                 // slots per lane before the run's end is looked at (G * NS0 <= 64)
+    uint32_t hits = 0;
     asm volatile("" : "+v"(lane));                      // per-lane constants are recomputed per window, not kept in registers
     const uint32_t j = lane & (G - 1), grp = lane / G;
     nh = __builtin_amdgcn_readfirstlane(nh);
     tot = __builtin_amdgcn_readfirstlane(tot);
-    const uint32_t x_lds = pc_lds_addr(L.x);
+    const uint32_t pt_lds = pc_lds_addr(L.pt);
     for (uint32_t base = 0; base < nh; base += H) {
-        const uint32_t e = L.home[base + grp];           // past nh: dead entries (odd NaN slot, empty run)
+        const uint32_t e = L.home[base + grp];           // past nh: dead entries (a NaN slot, an empty run)
         const uint32_t q = e & 0xFFFFu;
-        const float hx = L.x[q], hy = L.y[q], hz = L.z[q];
-        const pc_v2f ax = {hx, hx}, ay = {hy, hy}, az = {hz, hz};
-        uint32_t p = ((q + 1) >> 1) + j;                 // the lane's first pair
-        int rem = (int)(e >> 16) - (int)(2 * p);          // slots from there to the end of the run
-        // lane 0 of a group with an even home slot has the home particle itself in its first pair
-        selfs += __popcll(__builtin_amdgcn_ballot_w64(((q & 1u) | j) == 0u));
-        uint32_t ap = x_lds + 8 * p;
-        hits += pc_m_test<G, NP0>(ap, ax, ay, az);
-        rem -= 2 * G * NP0;
-        p += G * NP0;
+        const pc_v4f h = L.pt[q];
+        const pc_v2f hxy = {h.x, h.y};
+        const float hz = h.z;
+        uint32_t p = q + 1 + j;                          // the lane's first slot
+        int rem = (int)(e >> 16) - (int)p;                // slots from there to the end of the run
+        hits += pc_m_test<G, NS0>(pt_lds + 16 * p, hxy, hz);
+        rem -= G * NS0;
+        p += G * NS0;
         while (__builtin_amdgcn_ballot_w64(rem > 0) != 0) {
-            p = min(p, tot >> 1);                         // finished lanes wait on the never-matching slots
-            hits += pc_m_test<G, 1>(x_lds + 8 * p, ax, ay, az);
+            p = min(p, tot);                              // finished lanes wait on the never-matching slots
+            hits += pc_m_test<G, 2>(pt_lds + 16 * p, hxy, hz);
             rem -= 2 * G;
-            p += G;
+            p += 2 * G;
         }
     }
-    return hits - selfs;    // wave-uniform
+    return hits;    // wave-uniform
 }
 
 // The rest [z0, 400) of a pencil that this kernel does not process: onto the segment
@@ -220,8 +234,7 @@ pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T
                 n[r] = valid[r] ? a1[r] - a0[r] : 0u;
             }
             const uint32_t n_blk = n[0] + n[1] + n[2] + n[3] + n[4];
-            const uint32_t bs = (n_blk + 1) & ~1u;          // blocks start on even slots
-            const uint32_t cum = pc_wave_incl_scan(bs), cumh = pc_wave_incl_scan(n[0]);
+            const uint32_t cum = pc_wave_incl_scan(n_blk), cumh = pc_wave_incl_scan(n[0]);
             // blocks that fit (a prefix); the last two only supply candidates
             const int nblk = __popcll(__builtin_amdgcn_ballot_w64(cum <= PC_M_CAP && cumh <= PC_M_CAPH));
             const bool fits = nblk >= 3;
@@ -251,7 +264,7 @@ pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T
             done = pc_lane_value(s[0], w);                 // start of the first home cell of the next window
             if (nh != 0) {
                 if (lane >= nblk) { n[0] = 0; n[1] = 0; n[2] = 0; n[3] = 0; n[4] = 0; }
-                const uint32_t ex = cum - bs, exh = cumh - n[0];
+                const uint32_t ex = cum - n_blk, exh = cumh - n[0];
                 // end of S_{t+2}: the inclusive sum two lanes up
                 const uint32_t end2 = pc_from_lane_above(pc_from_lane_above(cum));
                 // ---- stage 1, lane = block: byte offsets of the block's points, row after row; home entries
@@ -269,23 +282,21 @@ pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T
                             if (v < n[r]) L.src[o + v] = 12u * (s[r] + v);
                         o += n[r];
                     }
-                    if (n_blk & 1u & (lane < nblk)) L.src[o] = 12u * home_lo;      // the pad slot copies any valid point ...
-                    // one step's worth of dead home entries: an odd slot in the never-matching tail, an empty run
-                    if (lane < 32) L.home[nh + lane] = (tot + 1) | ((tot + 1) << 16);
+                    // one step's worth of dead home entries: a slot of the never-matching tail, an empty run
+                    if (lane < 32) L.home[nh + lane] = tot | (tot << 16);
                 }
                 pc_wave_lds_sync();
                 // ---- stage 2, lane = slot: gather the points through the list, straight into LDS (no registers)
                 const char *bytes = reinterpret_cast<const char *>(pts);
-                for (uint32_t q0 = 0; q0 < tot; q0 += 64) {
-                    const uint32_t q = q0 + lane;
+                for (int q0 = (int)((tot - 1) & ~63u); q0 >= 0; q0 -= 64) {       // last chunk first: see pc_merge_lds
+                    const uint32_t q = (uint32_t)q0 + lane;
                     const uint32_t off = q < tot ? L.src[q] : 12u * home_lo;
-                    pc_dma_point(reinterpret_cast<const float *>(bytes + off), L.x + q0, L.y + q0, L.z + q0);
+                    pc_m_dma_point(bytes + off, L.pt + q0);
                 }
                 pc_dma_wait();
                 const float never = __builtin_nanf("");
-                if ((n_blk & 1u) && lane < nblk) L.x[ex + n_blk] = never;           // ... and then never matches
-                L.x[tot + lane] = never;
-                if (lane < PC_M_SLACK - 64) L.x[tot + 64 + lane] = never;
+                L.pt[tot + lane].x = never;
+                if (lane < PC_M_SLACK - 64) L.pt[tot + 64 + lane].x = never;
                 pc_wave_lds_sync();
                 // ---- the tests: group width from the mean run length (three blocks)
                 const uint32_t m3 = 3u * tot, blocks = (uint32_t)nblk;
