@@ -435,8 +435,15 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
         const uint32_t seg_cap = (uint32_t)g_segments.load(), heavy_cap = (uint32_t)g_heavy.load();   // one read each per call
         PC_HIP(hipMemsetAsync(queue, 0, PC_G_FLAGS * sizeof(unsigned int), (hipStream_t)stream));   // all counters
         const dim3 plan_grid(((x_hi - x_lo) * PC_NLAYERS + 255) / 256);
+        // a pencil holding more than four average pencils (and at least 512 points) counts as dense; an input with
+        // over a quarter of its points in such pencils is clustered: the merged-window kernel then leaves the
+        // whole job to the group kernel, which balances heavy pencils better
+        const uint64_t slab_pencils = (uint64_t)(x_hi < PC_NLAYERS ? x_hi - x_lo + 1 : x_hi - x_lo) * PC_NLAYERS;
+        const uint64_t full = 4 * n / slab_pencils;
+        const uint32_t full_pencil = (uint32_t)(full < 512 ? 512 : full > 0xFFFFFFFFull ? 0xFFFFFFFFull : full);
+        const uint32_t gate_limit = (uint32_t)(n / 4);
         PC_LAUNCH("pc_c3_plan", pc_c3_plan, plan_grid, dim3(256), (hipStream_t)stream, d_cell_start, x_lo, x_hi, queue,
-                  seg_cap);
+                  seg_cap, full_pencil);
         // as many workgroups as are resident at once (registers and LDS decide: asked of the runtime, once)
         static int resident_on[64];               // per device ordinal (count_queue has checked the range)
         int dev = 0;
@@ -466,15 +473,21 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
             }
             const int grid5 = ((r5 < most ? r5 : most) + 7) / 8 * 8;
             PC_LAUNCH("pc_c5_count_merged", pc_c5_count_merged, dim3(grid5), dim3(64), (hipStream_t)stream,
-                      d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, (unsigned long long *)d_npairs);
+                      d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, PC_GATE_IF_EVEN, gate_limit,
+                      (unsigned long long *)d_npairs);
         }
         const int grid = ((want < most ? want : most) + 7) / 8 * 8;
-        if (variant == 5)
+        if (variant == 5) {
             PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups<false>, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
-                      d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap, (unsigned long long *)d_npairs);
-        else
+                      d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap, PC_GATE_IF_EVEN, gate_limit,
+                      (unsigned long long *)d_npairs);
             PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups<true>, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
-                      d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap, (unsigned long long *)d_npairs);
+                      d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap, PC_GATE_IF_CLUSTERED, gate_limit,
+                      (unsigned long long *)d_npairs);
+        } else
+            PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups<true>, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
+                      d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap, PC_GATE_ALWAYS, 0u,
+                      (unsigned long long *)d_npairs);
         // the home particles of over-full cells that the waves listed instead of processing (normally none:
         // the workgroups then return at once)
         PC_LAUNCH("pc_c3_heavy", pc_c3_heavy, dim3(resident >= 2048 ? 2048 : resident), dim3(PC_G_HEAVY_CHUNK), (hipStream_t)stream,

@@ -54,6 +54,18 @@
 //   [PC_G_HEAVY_COUNT]               items appended
 //   [PC_G_HEAVY, +2*PC_G_HEAVY_CAP)  items: cell key (0xFFFFFFFF = void), chunk of 256 home particles
 #define PC_G_HEAVY_COUNT 304
+// points in pencils far fuller than the average one (counted by the planning kernel): a clustered input.
+// The kernels of one pair-test call take it as the switch between their two divisions of the work (PC_GATE_*).
+#define PC_G_DENSE_POINTS 296
+#define PC_GATE_ALWAYS 0
+#define PC_GATE_IF_EVEN 1            // run only if the dense points are at most the limit
+#define PC_GATE_IF_CLUSTERED 2       // run only if they are more
+__device__ __forceinline__ bool pc_gate_open(const unsigned int *queue, int gate, uint32_t limit)
+{
+    if (gate == PC_GATE_ALWAYS) return true;
+    const bool clustered = __builtin_amdgcn_readfirstlane(queue[PC_G_DENSE_POINTS]) > limit;
+    return (gate == PC_GATE_IF_CLUSTERED) == clustered;
+}
 #define PC_G_HEAVY (PC_G_SEGS + 2 * PC_G_SEG_CAP)
 #define PC_G_HEAVY_CAP 65536
 #define PC_G_HEAVY_CHUNK 256
@@ -340,7 +352,8 @@ __device__ __forceinline__ uint32_t pc_plan_walk(const uint32_t *__restrict__ ro
 }
 
 __global__ void __launch_bounds__(256)
-pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__restrict__ work, uint32_t seg_cap)
+pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__restrict__ work, uint32_t seg_cap,
+           uint32_t full_pencil)    // a pencil with more points than this counts as dense (several times the average)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= (x_hi - x_lo) * PC_NLAYERS) return;
@@ -348,7 +361,9 @@ pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__r
     const uint32_t pencil = (uint32_t)layer * PC_NBB + j;
     const uint32_t *row = T + (uint64_t)pencil * PC_NBB;
     unsigned char planned = 0;
-    if (row[PC_NLAYERS] - row[0] >= PC_G_PLAN_MIN_POINTS) {
+    const uint32_t population = row[PC_NLAYERS] - row[0];
+    if (population > full_pencil) atomicAdd(work + PC_G_DENSE_POINTS, population);
+    if (population >= PC_G_PLAN_MIN_POINTS) {
         const unsigned long long target = PC_G_PLAN_TARGET;
         const uint32_t segs = pc_plan_walk<false>(row, pencil, work, 0, target);
         if (segs >= 2) {
@@ -370,8 +385,9 @@ template <bool WHOLE_PENCILS>
 __global__ void __launch_bounds__(PC_G_WAVES * 64, 4)   // registers and LDS admit 5 waves per SIMD
 pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T, int x_lo, int x_hi,
                    unsigned int *__restrict__ queue, uint32_t seg_cap, uint32_t heavy_cap,
-                   unsigned long long *__restrict__ out)
+                   int gate, uint32_t gate_limit, unsigned long long *__restrict__ out)
 {
+    if (!pc_gate_open(queue, gate, gate_limit)) return;
     __shared__ pc_group_lds lds_all[PC_G_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     pc_group_lds &L = lds_all[wave];

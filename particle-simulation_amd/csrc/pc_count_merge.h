@@ -52,6 +52,15 @@
 #define PC_M_SLACK 80                   // never-matching slots behind the last block: a lane's first pass reads at most 65 past it
 #define PC_M_LEN (PC_M_CAP + PC_M_SLACK)
 #define PC_M_MAX_G 16
+#ifndef PC_M_NS8
+#define PC_M_NS8 8
+#endif
+#ifndef PC_M_G4_MAX
+#define PC_M_G4_MAX 28u                  // longest mean run (slots) that groups of four lanes take
+#endif
+#ifndef PC_M_UNROLL
+#define PC_M_UNROLL 3                    // points of a (cell, row) written without a loop
+#endif
 
 // A window in LDS: one 16-byte slot per point -- the layout a 12-byte LDS-DMA load writes (lane t's three
 // words land at byte 16 t of the destination, the fourth is left alone).
@@ -120,7 +129,7 @@ template <int G>
 __device__ __forceinline__ uint32_t pc_m_steps(const pc_merge_lds &L, uint32_t nh, uint32_t tot, int lane)
 {
     constexpr int H = 64 / G;
-    constexpr int NS0 = G <= 8 ? 8 : 4;                 // slots per lane before the run's end is looked at (G * NS0 <= 64)
+    constexpr int NS0 = G <= 4 ? 8 : G == 8 ? PC_M_NS8 : 4;   // slots per lane before the run's end is looked at (G * NS0 <= 64)
     uint32_t hits = 0;
     asm volatile("" : "+v"(lane));                      // per-lane constants are recomputed per window, not kept in registers
     const uint32_t j = lane & (G - 1), grp = lane / G;
@@ -172,8 +181,10 @@ __device__ __forceinline__ unsigned long long pc_m_defer(const float *__restrict
 
 __global__ void __launch_bounds__(64, 6)
 pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T, int x_lo, int x_hi,
-                   unsigned int *__restrict__ queue, uint32_t seg_cap, unsigned long long *__restrict__ out)
+                   unsigned int *__restrict__ queue, uint32_t seg_cap, int gate, uint32_t gate_limit,
+                   unsigned long long *__restrict__ out)
 {
+    if (!pc_gate_open(queue, gate, gate_limit)) return;
     __shared__ pc_merge_lds L;
     const int lane = threadIdx.x;
     unsigned long long acc = 0;          // per-lane partial (lane 0 also carries the wave-uniform hit counts)
@@ -268,17 +279,26 @@ pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T
                 // end of S_{t+2}: the inclusive sum two lanes up
                 const uint32_t end2 = pc_from_lane_above(pc_from_lane_above(cum));
                 // ---- stage 1, lane = block: byte offsets of the block's points, row after row; home entries
+                // (branch-free for the first PC_M_UNROLL points of a row: lanes that have none write to a spare word)
                 {
                     const uint32_t nhome = lane < w ? n[0] : 0u;
                     const uint32_t ent = ex | (end2 << 16);
-                    for (uint32_t v = 0; __builtin_amdgcn_ballot_w64(v < n[0]) != 0; v++) {
+                    const uint32_t spare = PC_M_LEN - 1;                  // last word of the list: never a slot's entry
+#pragma unroll
+                    for (uint32_t v = 0; v < PC_M_UNROLL; v++) {
+                        L.src[v < n[0] ? ex + v : spare] = 12u * (s[0] + v);
+                        L.home[v < nhome ? exh + v : PC_M_CAPH + 31] = ent + v;
+                    }
+                    for (uint32_t v = PC_M_UNROLL; __builtin_amdgcn_ballot_w64(v < n[0]) != 0; v++) {
                         if (v < n[0]) L.src[ex + v] = 12u * (s[0] + v);
                         if (v < nhome) L.home[exh + v] = ent + v;
                     }
                     uint32_t o = ex + n[0];
 #pragma unroll
                     for (int r = 1; r < 5; r++) {
-                        for (uint32_t v = 0; __builtin_amdgcn_ballot_w64(v < n[r]) != 0; v++)
+#pragma unroll
+                        for (uint32_t v = 0; v < PC_M_UNROLL; v++) L.src[v < n[r] ? o + v : spare] = 12u * (s[r] + v);
+                        for (uint32_t v = PC_M_UNROLL; __builtin_amdgcn_ballot_w64(v < n[r]) != 0; v++)
                             if (v < n[r]) L.src[o + v] = 12u * (s[r] + v);
                         o += n[r];
                     }
@@ -288,11 +308,17 @@ pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T
                 pc_wave_lds_sync();
                 // ---- stage 2, lane = slot: gather the points through the list, straight into LDS (no registers)
                 const char *bytes = reinterpret_cast<const char *>(pts);
-                for (int q0 = (int)((tot - 1) & ~63u); q0 >= 0; q0 -= 64) {       // last chunk first: see pc_merge_lds
-                    const uint32_t q = (uint32_t)q0 + lane;
-                    const uint32_t off = q < tot ? L.src[q] : 12u * home_lo;
-                    pc_m_dma_point(bytes + off, L.pt + q0);
+                // (all list reads first, then the copies, last chunk first: see pc_merge_lds)
+                constexpr int NCHUNK = (PC_M_CAP + 63) / 64;
+                uint32_t off[NCHUNK];
+#pragma unroll
+                for (int c = 0; c < NCHUNK; c++) {
+                    const uint32_t q = 64u * c + lane;
+                    off[c] = q < tot ? L.src[q] : 12u * home_lo;
                 }
+#pragma unroll
+                for (int c = NCHUNK - 1; c >= 0; c--)
+                    if (64u * c < tot) pc_m_dma_point(bytes + off[c], L.pt + 64 * c);
                 pc_dma_wait();
                 const float never = __builtin_nanf("");
                 L.pt[tot + lane].x = never;
@@ -306,7 +332,7 @@ pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T
                 if (m3 == 0xFFFFFFFFu)
 #endif
                 if (m3 <= 12u * blocks) hits = pc_m_steps<2>(L, nh, tot, lane);
-                else if (m3 <= 28u * blocks) hits = pc_m_steps<4>(L, nh, tot, lane);
+                else if (m3 <= PC_M_G4_MAX * blocks) hits = pc_m_steps<4>(L, nh, tot, lane);
                 else if (m3 <= 60u * blocks) hits = pc_m_steps<8>(L, nh, tot, lane);
                 else hits = pc_m_steps<16>(L, nh, tot, lane);
                 if (lane == 0) acc += hits;
