@@ -48,7 +48,7 @@ extern "C" const char *pc_version(void) { return "1.0 gfx950"; }
 static std::atomic<int> g_variant_bin{1};     // 0 = atomic counting sort, 1 = LDS-staged three-level bucket sort
 // 0 = global memory, 1 = LDS-tiled strips, 2 = wave per pencil, 3 = candidate-parallel groups,
 // 5 = merged single-run windows (variant 3's kernel for heavy pencils and what 5 defers),
-// 4 = by density: 0 below 0.8 points per cell of the slab on average, else 5
+// 4 = by density: 0 below 2/3 of a point per cell of the slab on average, else 5
 static std::atomic<int> g_variant_count{4};
 static std::atomic<int> g_heavy{PC_G_HEAVY_CAP};    // capacity of the list of over-full cells' home-particle chunks (0: never listed)
 static std::atomic<int> g_segments{PC_G_SEG_CAP};  // capacity of the heavy-pencil segment list (0: pencils are never cut)
@@ -416,10 +416,10 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
     if (n == 0 || x_lo == x_hi) return PC_OK;
     int variant = g_variant_count;
     if (variant == 4) {
-        // Sparse inputs: a window of 64 cells holds too few particles to pay for its bookkeeping, and the
-        // thread-per-particle kernel wins (measured crossover at 55 M uniform points = 0.86 per cell).
+        // Sparse inputs: a window of cells holds too few particles to pay for its bookkeeping, and the
+        // thread-per-particle kernel wins (measured crossover at 42 M uniform points = 0.66 per cell).
         const uint64_t cells = (uint64_t)(x_hi < PC_NLAYERS ? x_hi - x_lo + 1 : x_hi - x_lo) * PC_NLAYERS * PC_NLAYERS;
-        variant = n * 5 < cells * 4 ? 0 : 5;
+        variant = n * 3 < cells * 2 ? 0 : 5;
     }
     if (variant == 5 && n * 12 > 0xFFFFFFFFull) variant = 3;       // variant 5 addresses the sorted array by 32-bit byte offsets
     if (variant == 0) {

@@ -6,7 +6,7 @@
 // (offsets of main.c:195-209; the 403-wide padding keeps face aliasing empty),
 // and "later points of the same cell" are the sorted slots after the home
 // particle.  No staging and no per-window bookkeeping: the fastest form for sparse
-// inputs (below about 0.9 points per cell), where it is the default, and the
+// inputs (below about two thirds of a point per cell), where it is the default, and the
 // cross-check for the staged variants elsewhere.  pc_set_variant("count", 0).
 // The grid is capped by the host (grid-stride loop): every workgroup ends with
 // one atomic on the same address, and those serialise.
