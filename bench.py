@@ -150,10 +150,12 @@ def main():
         slab, slabs = args.as_rank
         total_points = args.points or (base_points * slabs if scaling == "weak" else base_points)
     if slabs > 1 and kind_name == "blobs":
-        # clustered input: cut where the estimated pair-test cost (layer population squared) balances
-        pop = ht.layer_histogram(kind, args.seed, total_points, sigma,
-                                 threads=max(1, min(16, (os.cpu_count() or 1) // max(world, 1)))).astype(np.float64)
-        cuts = sh.balanced_cuts(pop * pop, slabs)
+        # clustered input: cut where the estimated work balances (the reference's test count per layer from a
+        # block histogram of the stream, plus a per-point share for binning); the per-rank rows of the result
+        # line show how well it did
+        cost = ht.layer_cost(kind, args.seed, total_points, sigma,
+                             threads=max(1, min(16, (os.cpu_count() or 1) // max(world, 1))))
+        cuts = sh.balanced_cuts(cost, slabs)
     else:
         cuts = sh.equal_cuts(slabs)
     x_lo, x_hi = cuts[slab], cuts[slab + 1]

@@ -196,11 +196,14 @@ static int resident_blocks(K kernel, int tpb, int *slot)
 }
 
 // uint32 counters of the LDS variant, after its N*12-byte temp array
+// pencils of more than PC_L7B_CAP_LARGE points there can be among n points (plus slack)
+static constexpr size_t huge_rows(uint64_t n) { return (size_t)(n / PC_L7B_CAP_LARGE) + 2; }
+
 static constexpr size_t lds_ws_counters(uint64_t n)
 {
     return (size_t)PC_L_NREP * PC_L_BINS + (size_t)PC_L_NREP * PC_L_PSTRIDE + PC_L_BINS + (size_t)PC_L_NREP * PC_L_BINS + PC_L_BINS +
            ((n + PC_L_TILE - 1) / PC_L_TILE + PC_L_BINS) + (PC_L_NPENCILS + 1) + (size_t)PC_L_NREP * PC_L_PSTRIDE +
-           8 + PC_L_NPENCILS;
+           8 + PC_L_NPENCILS + huge_rows(n) * (1 + 2 * (size_t)PC_L_BINS);
 }
 
 static constexpr size_t workspace_bytes_for(uint64_t n)
@@ -228,7 +231,10 @@ static pc_lds_ws carve_lds_ws(void *ws, uint64_t n)
     w.tile_layer = u;             u += (n + PC_L_TILE - 1) / PC_L_TILE + PC_L_BINS;
     w.pencil_start = u;           u += PC_L_NPENCILS + 1;
     w.pencil_cursor = u;          u += PC_L_NREP * PC_L_PSTRIDE;
-    w.big_list = u;
+    w.big_list = u;               u += PC_L_NPENCILS;
+    w.huge_list = u;              u += huge_rows(n);
+    w.huge_count = u;             u += huge_rows(n) * PC_L_BINS;
+    w.huge_cursor = u;
     w.ycell = (uint16_t *)((char *)ws + align_up((size_t)n * 12 + 16, 256) + align_up(lds_ws_counters(n) * 4, 256));
     return w;
 }
@@ -271,9 +277,18 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
     auto large = pc_l7b_sort_big_pencils<PC_L7B_CAP_LARGE, PC_L7B_TPB_LARGE>;
     static int small_grid, large_grid;            // (one device model per process is assumed for these two)
     PC_LAUNCH("pc_l7b_sort_big_pencils", small, dim3(resident_blocks(small, PC_L7B_TPB_SMALL, &small_grid)), dim3(PC_L7B_TPB_SMALL), s, w.tmp, d_sorted, w.pencil_start, table,
-              w.big_count, w.big_list, first_pencil, end_pencil, 0u, (uint32_t)PC_L7B_CAP_SMALL, d_status);
+              w.big_count, w.big_list, first_pencil, end_pencil, 0u, (uint32_t)PC_L7B_CAP_SMALL,
+              (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, d_status);
     PC_LAUNCH("pc_l7b_sort_big_pencils", large, dim3(resident_blocks(large, PC_L7B_TPB_LARGE, &large_grid)), dim3(PC_L7B_TPB_LARGE), s, w.tmp, d_sorted, w.pencil_start, table,
-              w.big_count, w.big_list, first_pencil, end_pencil, (uint32_t)PC_L7B_CAP_SMALL, 0xFFFFFFFFu, d_status);
+              w.big_count, w.big_list, first_pencil, end_pencil, (uint32_t)PC_L7B_CAP_SMALL, (uint32_t)PC_L7B_CAP_LARGE,
+              w.big_count + 1, w.huge_list, w.huge_count, d_status);
+    // pencils beyond a workgroup's capacity (listed just now): tile-parallel histogram, scan, partition
+    PC_LAUNCH("pc_l7h_hist", pc_l7h_hist, dim3(PC_L7H_GRID), dim3(PC_L_TPB), s, w.tmp, w.pencil_start, w.big_count + 1,
+              w.huge_list, w.huge_count, d_status);
+    PC_LAUNCH("pc_l7h_scan", pc_l7h_scan, dim3(256), dim3(64), s, w.pencil_start, w.big_count + 1, w.huge_list,
+              w.huge_count, w.huge_cursor, table);
+    PC_LAUNCH("pc_l7h_partition", pc_l7h_partition, dim3(PC_L7H_GRID), dim3(PC_L_PTPB), s, w.tmp, d_sorted, w.pencil_start,
+              w.big_count + 1, w.huge_list, w.huge_cursor);
     PC_HIP(hipGetLastError());
     return PC_OK;
 }
@@ -490,7 +505,7 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
                       (unsigned long long *)d_npairs);
         // the home particles of over-full cells that the waves listed instead of processing (normally none:
         // the workgroups then return at once)
-        PC_LAUNCH("pc_c3_heavy", pc_c3_heavy, dim3(resident >= 2048 ? 2048 : resident), dim3(PC_G_HEAVY_CHUNK), (hipStream_t)stream,
+        PC_LAUNCH("pc_c3_heavy", pc_c3_heavy, dim3(resident >= 2048 ? 2048 : resident), dim3(PC_HV_TPB), (hipStream_t)stream,
                   d_sorted_xyz, d_cell_start, queue, heavy_cap, (unsigned long long *)d_npairs);
     } else if (variant == 2) {
         const int grid = 8 * (x_hi - x_lo) * PC_W_WG_PER_BAND;

@@ -48,6 +48,9 @@ struct pc_lds_ws {
     uint16_t *ycell;          // [N] y cell of every point of the level-X output (0xFFFF: outside the grid)
     uint32_t *big_count;      // [8] (first word used) number of entries of big_list; zeroed with the counters
     uint32_t *big_list;       // [162409] pencils with more points than one wave of L7 takes
+    uint32_t *huge_list;      // [n/8192+2] pencils with more points than one workgroup of L7B takes (count: big_count[1])
+    uint32_t *huge_count;     // [n/8192+2][404] their z-cell counts, then ...
+    uint32_t *huge_cursor;    // [n/8192+2][404] ... the write cursors of their cells
 };
 
 // ---- L1: histogram of x layers ---------------------------------------------
@@ -414,11 +417,11 @@ pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
 
 // ---- L7B: one workgroup sorts one big pencil ------------------------------------
 // Pencils with more points than a wave of L7 keeps (clustered inputs, or more than
-// about 2 points per cell everywhere) are listed by L5.  Up to CAP points go
-// through registers and an LDS copy in cell order like L7's; beyond that the
-// pencil is read twice (histogram, then scatter through LDS cursors).  Two
-// instantiations share the list: a small one (several workgroups per CU) takes
-// the pencils of at most PC_L7B_CAP_SMALL points, a large one the rest.
+// about 2 points per cell everywhere) are listed by L5.  Its points go through
+// registers and an LDS copy in cell order like L7's.  Two instantiations share the
+// list: a small one (several workgroups per CU) takes the pencils of at most
+// PC_L7B_CAP_SMALL points, a large one those of up to PC_L7B_CAP_LARGE; what is
+// larger still, the large one lists for the tile-parallel kernels (L7H below).
 #define PC_L7B_CAP_SMALL 2048
 #define PC_L7B_TPB_SMALL 256
 #define PC_L7B_CAP_LARGE 8192
@@ -430,6 +433,7 @@ pc_l7b_sort_big_pencils(const float *__restrict__ src, float *__restrict__ dst,
                         const uint32_t *__restrict__ pencil_start, uint32_t *__restrict__ table,
                         const uint32_t *__restrict__ big_count, const uint32_t *__restrict__ big_list,
                         uint32_t first_pencil, uint32_t end_pencil, uint32_t n_above, uint32_t n_upto,
+                        uint32_t *__restrict__ huge_n, uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count,
                         int32_t *__restrict__ status)
 {
     constexpr int PC_L7B_PPT = PC_L7B_CAP / PC_L7B_TPB;
@@ -442,13 +446,25 @@ pc_l7b_sort_big_pencils(const float *__restrict__ src, float *__restrict__ dst,
         const uint32_t pencil = big_list[b];
         if (pencil < first_pencil || pencil >= end_pencil) continue;          // workgroup-uniform
         const uint32_t base = pencil_start[pencil], n = pencil_start[pencil + 1] - base;
-        if (n <= n_above || n > n_upto) continue;                             // the other instantiation's
+        if (n <= n_above) continue;                                           // the other instantiation's
+        if (n > n_upto) {
+            // more than a workgroup sorts: the large instantiation lists the pencil for the tile-parallel kernels
+            // (pc_l7h_*) and clears its row of cell counts; the small one leaves it alone
+            if (huge_n != nullptr) {
+                __shared__ uint32_t slot;
+                __syncthreads();
+                if (tid == 0) { slot = atomicAdd(huge_n, 1u); huge_list[slot] = pencil; }
+                __syncthreads();
+                for (int k = tid; k < PC_L_BINS; k += PC_L7B_TPB) huge_count[(uint64_t)slot * PC_L_BINS + k] = 0;
+            }
+            continue;
+        }
         uint32_t *slice = table + (uint64_t)pencil * PC_NBB;
         const pc_pt3 *g = reinterpret_cast<const pc_pt3 *>(src) + base;
         __syncthreads();                                                     // previous pencil's LDS reads are done
         for (int k = tid; k < PC_L_BINS; k += PC_L7B_TPB) hist[k] = 0;
         __syncthreads();
-        if (n <= PC_L7B_CAP) {
+        {   // (n <= PC_L7B_CAP: larger pencils were handed over above)
             pc_pt3 pt[PC_L7B_PPT];
             uint32_t tag[PC_L7B_PPT];
 #pragma unroll
@@ -477,40 +493,155 @@ pc_l7b_sort_big_pencils(const float *__restrict__ src, float *__restrict__ dst,
             const uint32_t nd = 3u * hist[PC_L_BINS - 1];                     // bins 400..403 are empty: start of bin 403 = points kept
             float *od = dst + 3 * (uint64_t)base;
             for (uint32_t d = tid; d < nd; d += PC_L7B_TPB) od[d] = stage[d];
-        } else {
-            // (four points per thread and turn: four loads in flight -- a single workgroup is latency bound)
-            for (uint32_t i0 = tid; i0 < n; i0 += 4 * PC_L7B_TPB) {
-                float zz[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) zz[u] = g[min(i0 + u * PC_L7B_TPB, n - 1)].z;
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (i0 + u * PC_L7B_TPB < n) {
-                        const int k = pc_cell_index(zz[u]);
-                        if ((unsigned)k < 400u) atomicAdd(&hist[k], 1u);
-                        else bad = true;
-                    }
-                }
-            }
-            __syncthreads();
-            if (tid < 64) pc_l7_scan_bins(hist, tid);
-            __syncthreads();
-            for (int k = tid; k < PC_NBB; k += PC_L7B_TPB) slice[k] = base + hist[k];
-            __syncthreads();
-            pc_pt3 *o = reinterpret_cast<pc_pt3 *>(dst) + base;
-            for (uint32_t i0 = tid; i0 < n; i0 += 4 * PC_L7B_TPB) {
-                pc_pt3 v[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) v[u] = g[min(i0 + u * PC_L7B_TPB, n - 1)];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (i0 + u * PC_L7B_TPB < n) {
-                        const int k = pc_cell_index(v[u].z);
-                        if ((unsigned)k < 400u) o[atomicAdd(&hist[k], 1u)] = v[u];
-                    }
-                }
-            }
         }
     }
     if (bad) atomicOr(status, 1);
+}
+
+// ---- L7H: pencils too big for one workgroup, sorted by all of them -------------
+// A pencil with more than PC_L7B_CAP_LARGE points (many points in one place) is one more
+// level of the same bucket sort: tiles of 4096 points, histogram of z cells (LDS, then
+// one global atomic per tile and cell), scan, and a partition pass that sorts each tile
+// by cell in LDS and writes every cell's run with coalesced stores.  The pencils come
+// from the list the large L7B instantiation made; tile c of list entry h is taken by
+// workgroup (c + 7 h) mod gridDim, so that many entries with few tiles each spread out
+// over the grid as well as one entry with thousands.  Without such pencils the three
+// launches return at once.
+#define PC_L7H_GRID 1024
+__device__ __forceinline__ uint32_t pc_l7h_first_tile(uint32_t h)
+{
+    return (blockIdx.x + gridDim.x - (7u * h) % gridDim.x) % gridDim.x;
+}
+
+__global__ void __launch_bounds__(PC_L_TPB)
+pc_l7h_hist(const float *__restrict__ src, const uint32_t *__restrict__ pencil_start, const uint32_t *__restrict__ huge_n,
+            const uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count, int32_t *__restrict__ status)
+{
+    __shared__ uint32_t h_lds[PC_L_BINS];
+    const uint32_t entries = *huge_n;
+    bool bad = false;
+    for (uint32_t h = 0; h < entries; h++) {
+        const uint32_t pencil = huge_list[h];
+        const uint32_t base = pencil_start[pencil], n = pencil_start[pencil + 1] - base;
+        const uint32_t ntiles = (n + PC_L_TILE - 1) / PC_L_TILE;
+        const pc_pt3 *g = reinterpret_cast<const pc_pt3 *>(src) + base;
+        for (uint32_t t = pc_l7h_first_tile(h); t < ntiles; t += gridDim.x) {
+            const uint32_t first = t * PC_L_TILE, cnt = min((uint32_t)PC_L_TILE, n - first);
+            __syncthreads();
+            for (int b = threadIdx.x; b < PC_L_BINS; b += PC_L_TPB) h_lds[b] = 0;
+            __syncthreads();
+            float zs[PC_L_PPT];
+#pragma unroll
+            for (int j = 0; j < PC_L_PPT; j++) zs[j] = g[first + min((uint32_t)(threadIdx.x + j * PC_L_TPB), cnt - 1)].z;
+#pragma unroll
+            for (int j = 0; j < PC_L_PPT; j++) {
+                if ((uint32_t)(threadIdx.x + j * PC_L_TPB) < cnt) {
+                    const int k = pc_cell_index(zs[j]);
+                    if ((unsigned)k < 400u) atomicAdd(&h_lds[k], 1u);
+                    else bad = true;
+                }
+            }
+            __syncthreads();
+            for (int b = threadIdx.x; b < 400; b += PC_L_TPB)
+                if (h_lds[b]) atomicAdd(&huge_count[(uint64_t)h * PC_L_BINS + b], h_lds[b]);
+        }
+    }
+    if (bad) atomicOr(status, 1);
+}
+
+__global__ void __launch_bounds__(64)
+pc_l7h_scan(const uint32_t *__restrict__ pencil_start, const uint32_t *__restrict__ huge_n, const uint32_t *__restrict__ huge_list,
+            const uint32_t *__restrict__ huge_count, uint32_t *__restrict__ huge_cursor, uint32_t *__restrict__ table)
+{
+    __shared__ uint32_t hist[PC_L_BINS];
+    const uint32_t entries = *huge_n;
+    for (uint32_t h = blockIdx.x; h < entries; h += gridDim.x) {
+        const uint32_t pencil = huge_list[h], base = pencil_start[pencil];
+        for (int k = threadIdx.x; k < PC_L_BINS; k += 64) hist[k] = huge_count[(uint64_t)h * PC_L_BINS + k];
+        pc_wave_lds_sync();
+        pc_l7_scan_bins(hist, threadIdx.x);                // exclusive starts, in place
+        pc_wave_lds_sync();
+        uint32_t *slice = table + (uint64_t)pencil * PC_NBB;
+        for (int k = threadIdx.x; k < PC_L_BINS; k += 64) {
+            huge_cursor[(uint64_t)h * PC_L_BINS + k] = base + hist[k];
+            if (k < PC_NBB) slice[k] = base + hist[k];
+        }
+        pc_wave_lds_sync();
+    }
+}
+
+__global__ void __launch_bounds__(PC_L_PTPB)
+pc_l7h_partition(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ pencil_start,
+                 const uint32_t *__restrict__ huge_n, const uint32_t *__restrict__ huge_list,
+                 uint32_t *__restrict__ huge_cursor)
+{
+    __shared__ float buf[PC_L_TILE * 3];              // the tile sorted by cell
+    __shared__ uint16_t bin_of[PC_L_TILE];
+    __shared__ uint32_t hist[PC_L_BINS], lstart[PC_L_BINS], delta[PC_L_BINS];
+    const int tid = threadIdx.x;
+    const uint32_t entries = *huge_n;
+    for (uint32_t h = 0; h < entries; h++) {
+        const uint32_t pencil = huge_list[h];
+        const uint32_t base = pencil_start[pencil], n = pencil_start[pencil + 1] - base;
+        const uint32_t ntiles = (n + PC_L_TILE - 1) / PC_L_TILE;
+        uint32_t *cursor = huge_cursor + (uint64_t)h * PC_L_BINS;
+        for (uint32_t t = pc_l7h_first_tile(h); t < ntiles; t += gridDim.x) {
+            const uint32_t first = t * PC_L_TILE, cnt = min((uint32_t)PC_L_TILE, n - first);
+            const pc_pt3 *g = reinterpret_cast<const pc_pt3 *>(src) + base + first;
+            __syncthreads();                           // the previous tile's LDS reads are done
+            for (int b = tid; b < PC_L_BINS; b += PC_L_PTPB) hist[b] = 0;
+            pc_pt3 pt[PC_L_PPPT];
+#pragma unroll
+            for (int j = 0; j < PC_L_PPPT; j++) pt[j] = g[min((uint32_t)(tid + j * PC_L_PTPB), cnt - 1)];
+            __syncthreads();
+            uint32_t tag[PC_L_PPPT];                   // cell | rank << 10, or ~0 for "skip"
+#pragma unroll
+            for (int j = 0; j < PC_L_PPPT; j++) {
+                tag[j] = 0xFFFFFFFFu;
+                if ((uint32_t)(tid + j * PC_L_PTPB) < cnt) {
+                    const uint32_t b = (uint32_t)pc_cell_index(pt[j].z);
+                    if (b < 400u) tag[j] = b | (atomicAdd(&hist[b], 1u) << 10);
+                }
+            }
+            __syncthreads();
+            if (tid < 64) {                            // exclusive scan of the tile's cell counts
+                uint32_t c[7], sum = 0;
+#pragma unroll
+                for (int q = 0; q < 7; q++) {
+                    const int b = tid * 7 + q;
+                    c[q] = b < PC_L_BINS ? hist[b] : 0u;
+                    sum += c[q];
+                }
+                uint32_t run = pc_wave_incl_scan(sum) - sum;
+#pragma unroll
+                for (int q = 0; q < 7; q++) {
+                    const int b = tid * 7 + q;
+                    if (b < PC_L_BINS) lstart[b] = run;
+                    run += c[q];
+                }
+            }
+            __syncthreads();
+            for (int b = tid; b < PC_L_BINS; b += PC_L_PTPB) {      // claim global space: one atomic per non-empty cell
+                const uint32_t c = hist[b];
+                if (c) delta[b] = atomicAdd(&cursor[b], c) - lstart[b];
+            }
+#pragma unroll
+            for (int j = 0; j < PC_L_PPPT; j++) {
+                if (tag[j] != 0xFFFFFFFFu) {
+                    const uint32_t b = tag[j] & 1023u, pos = lstart[b] + (tag[j] >> 10);
+                    buf[3 * pos] = pt[j].x;
+                    buf[3 * pos + 1] = pt[j].y;
+                    buf[3 * pos + 2] = pt[j].z;
+                    bin_of[pos] = (uint16_t)b;
+                }
+            }
+            __syncthreads();
+            const uint32_t kept = lstart[PC_L_BINS - 1] + hist[PC_L_BINS - 1];
+            for (uint32_t d = tid; d < 3 * kept; d += PC_L_PTPB) {   // runs -> global, coalesced dwords
+                const uint32_t e = d / 3u;
+                const uint32_t slot = delta[bin_of[e]] + e;
+                dst[3 * (uint64_t)slot + (d - 3u * e)] = buf[d];
+            }
+        }
+    }
 }

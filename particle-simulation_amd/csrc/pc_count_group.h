@@ -696,47 +696,113 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
     pc_block_add_u64<PC_G_WAVES>(acc, out);
 }
 
-// The listed home particles of over-full cells: one thread per home particle, its
-// candidates (the cell's later slots and the cell above, then the three-cell runs of
-// the four neighbour pencils: main.c:195-221) read through the caches -- every
-// thread of a workgroup walks the same ranges, so the reads are broadcasts.
-__global__ void __launch_bounds__(PC_G_HEAVY_CHUNK)
+// The listed home particles of over-full cells.  A workgroup takes one list item -- 256
+// home particles of one cell, two per thread, in registers -- and streams the cell's
+// candidates (its later slots and the cell above, then the three-cell runs of the four
+// neighbour pencils: main.c:195-221) through an LDS tile of 256 points; every thread
+// walks the whole tile, so the LDS reads are broadcasts and each serves two tests.
+// Only the tile that holds the home particles themselves needs the "later slots only"
+// rule (main.c:215-219) as a mask.  Missing home particles and tile padding are NaN
+// points, which never match.
+#define PC_HV_TPB 128
+#define PC_HV_TILE 256
+typedef float pc_hv4 __attribute__((ext_vector_type(4)));
+
+// one candidate tile [t0, t0 + cnt) of the sorted array against the two home particles of every thread;
+// MASKED: candidate slot q pairs with a home particle in slot p only if q > p (i0, i1 = p - t0)
+template <bool MASKED>
+__device__ __forceinline__ uint32_t pc_hv_tile(const float *__restrict__ pts, pc_hv4 *tile, uint32_t t0, uint32_t cnt,
+                                               pc_v2f h0xy, float h0z, pc_v2f h1xy, float h1z, int i0, int i1)
+{
+    struct pt3 { float x, y, z; };
+    const pt3 *P = reinterpret_cast<const pt3 *>(pts);
+    const float never = __builtin_nanf("");
+    __syncthreads();                                   // the previous tile has been read
+#pragma unroll
+    for (int u = 0; u < PC_HV_TILE / PC_HV_TPB; u++) {
+        const uint32_t e = threadIdx.x + u * PC_HV_TPB;
+        pc_hv4 v = {never, never, never, never};
+        if (e < cnt) { const pt3 c = P[t0 + e]; v.x = c.x; v.y = c.y; v.z = c.z; }
+        tile[e] = v;
+    }
+    __syncthreads();
+    uint32_t hits = 0;
+    const int rounds = (int)((cnt + 3) & ~3u);         // (padding entries are NaN)
+    for (int i = 0; i < rounds; i += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const pc_hv4 c = tile[i + u];               // the same address in every lane: a broadcast
+            const pc_v2f cxy = {c.x, c.y};
+            // (dx*dx + dy*dy) + dz*dz, each step rounded separately (no contraction: see build flags)
+            const pc_v2f d0 = h0xy - cxy, d1 = h1xy - cxy;
+            const float e0 = h0z - c.z, e1 = h1z - c.z;
+            const pc_v2f q0 = d0 * d0, q1 = d1 * d1;
+            const float s0 = (q0.x + q0.y) + e0 * e0, s1 = (q1.x + q1.y) + e1 * e1;
+            unsigned long long b0 = __builtin_amdgcn_ballot_w64(s0 <= 0.0025f), b1 = __builtin_amdgcn_ballot_w64(s1 <= 0.0025f);
+            if (MASKED) {
+                b0 &= __builtin_amdgcn_ballot_w64(i + u > i0);
+                b1 &= __builtin_amdgcn_ballot_w64(i + u > i1);
+            }
+            hits += __popcll(b0) + __popcll(b1);
+        }
+    }
+    return hits;
+}
+
+__global__ void __launch_bounds__(PC_HV_TPB)
 pc_c3_heavy(const float *__restrict__ pts, const uint32_t *__restrict__ T, const unsigned int *__restrict__ work,
             uint32_t heavy_cap, unsigned long long *__restrict__ out)
 {
+    static_assert(PC_G_HEAVY_CHUNK == 2 * PC_HV_TPB && PC_HV_TILE == PC_G_HEAVY_CHUNK, "two home particles per thread, home chunk = one tile");
     const uint32_t items = min(work[PC_G_HEAVY_COUNT], heavy_cap);
     if (items == 0) return;
+    __shared__ pc_hv4 tile[PC_HV_TILE];
     struct pt3 { float x, y, z; };
     const pt3 *P = reinterpret_cast<const pt3 *>(pts);
-    unsigned long long acc = 0;
-    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+    const float never = __builtin_nanf("");
+    unsigned long long acc = 0;            // wave-uniform hit counts: lane 0 of each wave carries them
+    // The unit of work is (item, candidate tile): an item's tiles are dealt out over the whole grid -- tile t of
+    // item i goes to workgroup (t + 7 i) mod gridDim -- so that a single over-full cell keeps every CU busy.
+    for (uint32_t item = 0; item < items; item++) {
         const uint32_t key = work[PC_G_HEAVY + 2 * item], chunk = work[PC_G_HEAVY + 2 * item + 1];
         if (key == 0xFFFFFFFFu) continue;
-        const uint32_t p = T[key] + chunk * PC_G_HEAVY_CHUNK + threadIdx.x;
-        if (p >= T[key + 1]) continue;
-        const pt3 me = P[p];
+        const uint32_t cell_hi = T[key + 1];
+        const uint32_t h0 = T[key] + chunk * PC_G_HEAVY_CHUNK;         // first home slot of the item
+        if (h0 >= cell_hi) continue;
+        // the five candidate ranges and their tile counts: the same pencil from the item's own slots to the end of
+        // the cell above (its first tile is the item itself), then the three-cell runs of the four neighbour pencils
         const uint32_t base[5] = {0u, 402u, 162005u, 162408u, 162811u};
-        uint32_t lo[5], hi[5];
-        lo[0] = p + 1;
-        hi[0] = T[key + 2];
-#pragma unroll
-        for (int r = 1; r < 5; r++) {
-            lo[r] = T[key + base[r]];
-            hi[r] = T[key + base[r] + 3];
-        }
-        const pc_v2f ax = {me.x, me.x}, ay = {me.y, me.y}, az = {me.z, me.z};
-        uint32_t cnt = 0;
+        uint32_t lo[5], first_tile[6];
+        first_tile[0] = 0;
 #pragma unroll
         for (int r = 0; r < 5; r++) {
-            for (uint32_t q = lo[r]; q < hi[r]; q += 2) {
-                const pt3 v0 = P[q], v1 = P[min(q + 1, hi[r] - 1)];
-                const pc_v2f cx = {v0.x, v1.x}, cy = {v0.y, v1.y}, cz = {v0.z, v1.z};
-                const pc_v2f dx = ax - cx, dy = ay - cy, dz = az - cz;
-                const pc_v2f sq = (dx * dx + dy * dy) + dz * dz;         // unfused: see the build flags
-                cnt += (sq.x <= 0.0025f) + ((sq.y <= 0.0025f) & (q + 1 < hi[r]));
-            }
+            lo[r] = r == 0 ? h0 : T[key + base[r]];
+            const uint32_t hi = r == 0 ? T[key + 2] : T[key + base[r] + 3];
+            first_tile[r + 1] = first_tile[r] + (hi - lo[r] + PC_HV_TILE - 1) / PC_HV_TILE;
         }
-        acc += cnt;
+        uint32_t t = (blockIdx.x + gridDim.x - (7u * item) % gridDim.x) % gridDim.x;
+        if (t >= first_tile[5]) continue;
+        const uint32_t p0 = h0 + threadIdx.x, p1 = p0 + PC_HV_TPB;
+        pt3 m0 = {never, never, never}, m1 = {never, never, never};
+        if (p0 < cell_hi) m0 = P[p0];
+        if (p1 < cell_hi) m1 = P[p1];
+        const pc_v2f h0xy = {m0.x, m0.y}, h1xy = {m1.x, m1.y};
+        uint32_t hits = 0;
+        for (; t < first_tile[5]; t += gridDim.x) {
+            int r = 0;
+#pragma unroll
+            for (int q = 1; q < 5; q++) r += t >= first_tile[q];
+            uint32_t lo_r = lo[0], hi_r = T[key + 2], ft = 0;
+#pragma unroll
+            for (int q = 1; q < 5; q++)
+                if (r == q) { lo_r = lo[q]; hi_r = T[key + base[q] + 3]; ft = first_tile[q]; }
+            const uint32_t t0 = lo_r + (t - ft) * PC_HV_TILE, cnt = min((uint32_t)PC_HV_TILE, hi_r - t0);
+            if (t == 0)
+                hits += pc_hv_tile<true>(pts, tile, t0, cnt, h0xy, m0.z, h1xy, m1.z, (int)threadIdx.x, (int)threadIdx.x + PC_HV_TPB);
+            else
+                hits += pc_hv_tile<false>(pts, tile, t0, cnt, h0xy, m0.z, h1xy, m1.z, 0, 0);
+        }
+        if ((threadIdx.x & 63) == 0) acc += hits;
     }
-    pc_block_add_u64<PC_G_HEAVY_CHUNK / 64>(acc, out);
+    pc_block_add_u64<PC_HV_TPB / 64>(acc, out);
 }

@@ -434,3 +434,63 @@ int xyz_layer_histogram(int kind, uint64_t seed, int64_t sigma_micro, uint64_t f
     free(jobs);
     return 0;
 }
+
+/* Estimated work per occupied x layer (400 numbers) of stream points [first, first+count), for placing slab
+   cuts that balance TIME rather than points: the reference's test count for a home cell with n points amid
+   equally full neighbours is about 13.5 n^2 (n(n-1)/2 + n * 13 n, main.c:210-229), estimated here from a
+   histogram over blocks of 8x8 cells per layer (population^2 / 64 per block), plus a fixed number of
+   test-equivalents per point for the binning and the pair test's per-point work. */
+#define XYZ_COST_BLOCK 8
+#define XYZ_COST_NB (400 / XYZ_COST_BLOCK)
+typedef struct { int kind; uint64_t seed; int64_t sigma; uint64_t first, count; uint32_t *blocks; } cost_job;
+
+static void *cost_worker(void *arg)
+{
+    cost_job *j = (cost_job *)arg;
+    for (uint64_t i = j->first; i < j->first + j->count; i++) {
+        int64_t m[3];
+        xyz_point_micro(j->kind, j->seed, i, j->sigma, m);
+        const int cx = xyz_cell_index(xyz_micro_to_float(m[0])), cy = xyz_cell_index(xyz_micro_to_float(m[1])),
+                  cz = xyz_cell_index(xyz_micro_to_float(m[2]));
+        if (cx >= 0 && cx < 400 && cy >= 0 && cy < 400 && cz >= 0 && cz < 400)
+            j->blocks[((size_t)cx * XYZ_COST_NB + cy / XYZ_COST_BLOCK) * XYZ_COST_NB + cz / XYZ_COST_BLOCK]++;
+    }
+    return NULL;
+}
+
+int xyz_layer_cost(int kind, uint64_t seed, int64_t sigma_micro, uint64_t first, uint64_t count,
+                   double per_point, double *cost400, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 64) nthreads = 64;
+    const size_t nb = (size_t)400 * XYZ_COST_NB * XYZ_COST_NB;
+    cost_job jobs[64];
+    pthread_t th[64];
+    int threaded[64];
+    const uint64_t per = (count + (uint64_t)nthreads - 1) / (uint64_t)nthreads;
+    for (int t = 0; t < nthreads; t++) {
+        uint64_t b = (uint64_t)t * per; if (b > count) b = count;
+        uint64_t e = b + per > count ? count : b + per;
+        jobs[t] = (cost_job){kind, seed, sigma_micro, first + b, e - b, (uint32_t *)calloc(nb, sizeof(uint32_t))};
+        if (!jobs[t].blocks) { for (int u = 0; u < t; u++) free(jobs[u].blocks); return -3; }
+        threaded[t] = 0;
+    }
+    for (int t = 1; t < nthreads; t++) {
+        threaded[t] = pthread_create(&th[t], NULL, cost_worker, &jobs[t]) == 0;
+        if (!threaded[t]) cost_worker(&jobs[t]);
+    }
+    cost_worker(&jobs[0]);
+    for (int t = 1; t < nthreads; t++) if (threaded[t]) pthread_join(th[t], NULL);
+    for (int l = 0; l < 400; l++) {
+        double tests = 0, pop = 0;
+        for (size_t b = (size_t)l * XYZ_COST_NB * XYZ_COST_NB; b < (size_t)(l + 1) * XYZ_COST_NB * XYZ_COST_NB; b++) {
+            double p = 0;
+            for (int t = 0; t < nthreads; t++) p += jobs[t].blocks[b];
+            pop += p;
+            tests += 13.5 * p * p / (XYZ_COST_BLOCK * XYZ_COST_BLOCK);
+        }
+        cost400[l] = tests + per_point * pop;
+    }
+    for (int t = 0; t < nthreads; t++) free(jobs[t].blocks);
+    return 0;
+}

@@ -38,6 +38,8 @@ def lib():
                                    c.c_char_p, c.c_int]
         L.xyz_layer_histogram.restype = c.c_int
         L.xyz_layer_histogram.argtypes = [c.c_int, c.c_uint64, c.c_int64, c.c_uint64, c.c_uint64, c.c_void_p, c.c_int]
+        L.xyz_layer_cost.restype = c.c_int
+        L.xyz_layer_cost.argtypes = [c.c_int, c.c_uint64, c.c_int64, c.c_uint64, c.c_uint64, c.c_double, c.c_void_p, c.c_int]
         L.xyz_filter_slab.restype = c.c_int64
         L.xyz_filter_slab.argtypes = [c.c_void_p, c.c_uint64, c.c_int, c.c_int, c.c_void_p]
         _lib = L
@@ -110,6 +112,17 @@ def layer_histogram(kind, seed, count, sigma_micro=0, first=0, threads=None):
     if rc != 0:
         raise RuntimeError("xyz_layer_histogram failed: %d" % rc)
     return hist
+
+
+def layer_cost(kind, seed, count, sigma_micro=0, first=0, per_point=40.0, threads=None):
+    """Estimated work per occupied x layer (400 entries, in units of one reference distance test) of a
+    synthetic stream: 13.5 n^2 per cell estimated over blocks of 8x8 cells, plus `per_point` per point."""
+    cost = np.zeros(400, dtype=np.float64)
+    rc = lib().xyz_layer_cost(kind, seed, sigma_micro, first, count, float(per_point), cost.ctypes.data,
+                              threads or host_threads())
+    if rc != 0:
+        raise RuntimeError("xyz_layer_cost failed: %d" % rc)
+    return cost
 
 
 def filter_slab(xyz, x_lo, x_hi):

@@ -37,6 +37,13 @@ def dev(torch_mod, a):
     return torch_mod.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to("cuda:0")
 
 
+def _cell_box(rng, n, lo_cell, hi_cell):
+    """n points uniform inside the box of cells [lo_cell, hi_cell) (per axis), kept clear of the box faces."""
+    lo = np.asarray(lo_cell, np.float64) * 0.05 - 10.0 + 1e-4
+    hi = np.asarray(hi_cell, np.float64) * 0.05 - 10.0 - 1e-4
+    return rng.uniform(lo, hi, (n, 3))
+
+
 VARIANTS = [(1, 4), (1, 5), (1, 3), (0, 0), (1, 1), (0, 2)]      # (binning variant, pair-test variant; 4 = chosen by density)
 
 
@@ -114,7 +121,8 @@ def test_golden_fixture_counts(psa, stages, torch_mod, golden_dir):
 
 
 @pytest.mark.parametrize("kind,n,seed", [("uniform", 200_000, 1), ("uniform", 2_000_000, 2),
-                                         ("box", 300_000, 3), ("blobs", 400_000, 4), ("one_cell", 3000, 5)])
+                                         ("box", 300_000, 3), ("blobs", 400_000, 4), ("one_cell", 3000, 5),
+                                         ("huge_pencils", 120_000, 6)])
 def test_seeded_inputs_match_oracle(psa, stages, torch_mod, oracle, kind, n, seed):
     rng = np.random.default_rng(seed)
     if kind == "uniform":
@@ -124,6 +132,12 @@ def test_seeded_inputs_match_oracle(psa, stages, torch_mod, oracle, kind, n, see
     elif kind == "blobs":
         c = rng.uniform(-8, 8, (16, 3))
         xyz = np.clip(c[rng.integers(0, 16, n)] + rng.normal(0, 0.12, (n, 3)), -9.999, 9.999)
+    elif kind == "huge_pencils":             # pencils beyond one workgroup's sorting capacity (8192 points), side by side
+        xyz = np.concatenate([_cell_box(rng, 40_000, (77, 200, 0), (78, 201, 400)),
+                              _cell_box(rng, 9_000, (77, 201, 0), (78, 202, 400)),
+                              _cell_box(rng, 8_193, (78, 200, 0), (79, 201, 400)),
+                              _cell_box(rng, 20_000, (399, 399, 100), (400, 400, 103)),      # ... and one with three full cells
+                              rng.uniform(-9.999, 9.999, (n - 77_193, 3))])
     else:                                    # everything inside one cell: n(n-1)/2 tests
         xyz = rng.uniform(0.001, 0.049, (n, 3))
     xyz = xyz.astype(np.float32)
@@ -358,13 +372,6 @@ def test_config3_size_properties(psa, torch_mod):
         total += st.pairs()
         total_tests += st.tests()
     assert total == whole and total_tests == tests
-
-
-def _cell_box(rng, n, lo_cell, hi_cell):
-    """n points uniform inside the box of cells [lo_cell, hi_cell) (per axis), kept clear of the box faces."""
-    lo = np.asarray(lo_cell, np.float64) * 0.05 - 10.0 + 1e-4
-    hi = np.asarray(hi_cell, np.float64) * 0.05 - 10.0 - 1e-4
-    return rng.uniform(lo, hi, (n, 3))
 
 
 @pytest.mark.parametrize("shape", ["pencil", "two_pencils", "sheet", "gradient", "needle_in_dust", "layer_pair", "heavy_block"])

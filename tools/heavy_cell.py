@@ -13,7 +13,10 @@ for n in (20_000, 50_000, 100_000, 200_000):
     for variant in (3, 0):
         psa.set_variant("count", variant)
         st.count_pairs(xyz); torch.cuda.synchronize()
+        psa.profile_enable(True)
         t = time.time(); st.count_pairs(xyz); torch.cuda.synchronize(); dt = time.time() - t
+        psa.profile_enable(False)
         st.count_tests()
         print("n %7d variant %d: %.1f ms, pairs %d, tests %d (%.2e tests/s)" % (n, variant, dt * 1e3, st.pairs(), st.tests(), st.tests() / dt), flush=True)
+        print("      " + ", ".join("%s %.3f" % (k, v[2]) for k, v in psa.profile_read().items() if v[2] > 0.02), flush=True)
 psa.set_variant("count", 4)
