@@ -40,6 +40,25 @@ extern "C" {
 
 typedef struct pc_context pc_context;
 
+/* Geometry of a run.  The reference compiles it in (main.c:30-31 BBSIZE 0.05 and the
+   domain from -10, main.c:134-136 the cell formula, main.c:165 the threshold 0.0025);
+   pc_geometry_default() is exactly that, and every entry point without a geometry
+   argument uses it.  Other values go through the same arithmetic:
+       cell(f) = (int)(((double)f - origin) / cell)      per axis, valid cells 0 .. ncell-1
+       a pair counts if (dx*dx + dy*dy) + dz*dz <= d2max   (unfused binary32)
+   Requirements: 1 <= ncell <= PC_NLAYERS (the table keeps 403 cells per axis; a point
+   that maps to a cell >= ncell is outside the domain), and the cutoff must not exceed
+   the cell edge: d2max <= cell*cell*(1 - 1e-5) unless all three values are the
+   reference's.  There is no reference program for other geometries: their results
+   are checked against a brute-force count (tests), not pinned by the reference. */
+typedef struct pc_geometry {
+    double origin;   /* lower bound of the domain on every axis   (reference: -10.0)  */
+    double cell;     /* cell edge                                 (reference: 0.05)   */
+    int32_t ncell;   /* occupied cells per axis                   (reference: 400)    */
+    float d2max;     /* squared cutoff                            (reference: 0.0025f)*/
+} pc_geometry;
+int pc_geometry_default(pc_geometry *g);
+
 const char *pc_last_error(void);
 /* "major.minor" of this ABI and the gfx target the kernels were built for. */
 const char *pc_version(void);
@@ -57,6 +76,10 @@ int pc_create(pc_context **ctx, int device, uint64_t expected_points);
    main.c:195-209 has di in {0,+1}).  Default is the whole grid, [0, 400).
    No counterpart in the reference (single process). */
 int pc_set_slab(pc_context *ctx, int x_lo, int x_hi);
+
+/* Gives the context another geometry than the reference's (any time before
+   pc_finish).  PC_ERR_ARG for values outside the requirements above. */
+int pc_set_geometry(pc_context *ctx, const pc_geometry *g);
 
 /* Replaces the per-point sink insert(hm, key, val) (hashmap.h:33,94; called
    from every parser thread at main.c:137).  Appends n points given as packed
@@ -149,6 +172,18 @@ int pc_count_pairs_device(const float *d_xyz, uint64_t n, int x_lo, int x_hi,
                           float *d_sorted_xyz, uint32_t *d_cell_start,
                           void *d_workspace, size_t workspace_bytes,
                           uint64_t *d_npairs, int32_t *d_status, void *stream);
+
+/* pc_cell_keys_device, pc_count_pairs_device and pc_selfcheck_cell_index_device with
+   an explicit geometry (see pc_geometry); with pc_geometry_default() they are the
+   calls above, bit for bit.  No counterpart in the reference (main.c:30-31,165
+   are compile-time constants there). */
+int pc_cell_keys_geometry_device(const pc_geometry *g, const float *d_xyz, uint64_t n, uint32_t *d_keys,
+                                 int32_t *d_status, void *stream);
+int pc_count_pairs_geometry_device(const pc_geometry *g, const float *d_xyz, uint64_t n, int x_lo, int x_hi,
+                                   float *d_sorted_xyz, uint32_t *d_cell_start,
+                                   void *d_workspace, size_t workspace_bytes,
+                                   uint64_t *d_npairs, int32_t *d_status, void *stream);
+int pc_selfcheck_cell_index_geometry_device(const pc_geometry *g, uint64_t *d_mismatches, void *stream);
 
 /* The same call for callers that cannot allocate device memory (code under HIP
    graph capture, tight serving loops, harnesses that forbid hipMalloc): no

@@ -7,10 +7,11 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
  *
  * Parity status: PINNED.  Every function below is compared, in
- * tests/golden/make_golden.py and tests/test_oracle_vs_ref.py, against the
+ * tests/golden/make_golden.py (vectors) and tests/test_oracle_golden.py (check), against the
  * unmodified reference compiled from /root/reference/src (oracle/ref_shim.c,
  * built into oracle/_ref/), and the resulting vectors are committed under
  * tests/golden/.  The reference itself ships no tests or fixtures.
+ * (Only with the reference's own geometry: see orc_set_geometry.)
  *
  * Each function cites the reference file:line it restates.
  *
@@ -155,9 +156,24 @@ int64_t orc_parse_buffer(const char *buf, uint64_t len, float *xyz, uint64_t cap
 /* ------------------------------------------------------------------------- */
 /* Cell index and key: reference main.c:30-32, 134-137.                        */
 /* ------------------------------------------------------------------------- */
+/* The reference compiles the geometry in (main.c:30-31, 134-136, 165).  The checker can be given another one --
+   same expressions, other constants -- for the product's configurable geometry; nothing of the reference
+   pins those results (it has no such option): they are checked against orc_count_pairs_anycell below. */
+static double orc_origin = -10., orc_cell = 0.05, orc_d2max = 0.0025;
+static int orc_ncell = 400;
+
+void orc_set_geometry(double origin, double cell, int ncell, float d2max)
+{
+    orc_origin = origin;
+    orc_cell = cell;
+    orc_ncell = ncell;
+    /* the reference compares (double)d2 <= 0.0025 (the double literal); for its own threshold keep exactly that */
+    orc_d2max = d2max == 0.0025f ? 0.0025 : (double)d2max;
+}
+
 int orc_cell_index(float f)
 {
-    return (int)((f - (-10.)) / 0.05);    /* float promoted to double, IEEE divide */
+    return (int)((f - orc_origin) / orc_cell);    /* float promoted to double, IEEE divide; defaults: (f - (-10.)) / 0.05 */
 }
 
 int64_t orc_cell_key(float x, float y, float z)
@@ -188,14 +204,14 @@ float orc_dist2(const float *a, const float *b)
     return lo + hi;
 }
 
-int orc_within(float d2) { return d2 <= 0.0025; }   /* double compare, main.c:165 */
+int orc_within(float d2) { return d2 <= orc_d2max; }   /* double compare, main.c:165 */
 
 static inline int pair_hit(const float *a, const float *b)
 {
     float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
     float s = dx * dx + dy * dy;          /* -ffp-contract=off: no fusion */
     s = s + dz * dz;
-    return (double)s <= 0.0025;
+    return (double)s <= orc_d2max;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -281,7 +297,7 @@ int64_t orc_count_pairs(const float *xyz, uint64_t n, int nthreads, int x_lo, in
     for (uint64_t p = 0; p < n; p++) {
         int i = orc_cell_index(xyz[3 * p]), j = orc_cell_index(xyz[3 * p + 1]),
             k = orc_cell_index(xyz[3 * p + 2]);
-        if (i < 0 || i >= 400 || j < 0 || j >= 400 || k < 0 || k >= 400) {
+        if (i < 0 || i >= orc_ncell || j < 0 || j >= orc_ncell || k < 0 || k >= orc_ncell) {
             free(start); free(keys); if (!sorted_out) free(sorted);
             return -1;
         }
@@ -344,6 +360,17 @@ int64_t orc_count_pairs_bruteforce(const float *xyz, uint64_t n)
             cnt += orc_within(orc_dist2(xyz + 3 * a, xyz + 3 * b));
         }
     }
+    return cnt;
+}
+
+/* Brute force over ALL pairs, no cell condition: what "pairs within the cutoff" means when no grid is given.
+ * Equal to the stencil count whenever the cutoff does not exceed the cell edge (then points two cells apart
+ * cannot be within it). */
+int64_t orc_count_pairs_anycell(const float *xyz, uint64_t n)
+{
+    int64_t cnt = 0;
+    for (uint64_t a = 0; a < n; a++)
+        for (uint64_t b = a + 1; b < n; b++) cnt += orc_within(orc_dist2(xyz + 3 * a, xyz + 3 * b));
     return cnt;
 }
 

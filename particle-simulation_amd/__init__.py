@@ -53,12 +53,28 @@ ABI = [
     ("pc_count_tests_device", _i32, [_vp, _i32, _i32, _vp, _vp]),
     ("pc_count_pairs_device", _i32, [_vp, _u64, _i32, _i32, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     ("pc_count_pairs_noalloc", _i32, [_vp, _u64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    ("pc_geometry_default", _i32, [_vp]),
+    ("pc_set_geometry", _i32, [_vp, _vp]),
+    ("pc_cell_keys_geometry_device", _i32, [_vp, _vp, _u64, _vp, _vp, _vp]),
+    ("pc_count_pairs_geometry_device", _i32, [_vp, _vp, _u64, _i32, _i32, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    ("pc_selfcheck_cell_index_geometry_device", _i32, [_vp, _vp, _vp]),
     ("pc_set_variant", _i32, [_c.c_char_p, _i32]),
     ("pc_profile_enable", _i32, [_i32]),
     ("pc_profile_read", _i32, [_c.c_char_p, _sz]),
     ("pc_selfcheck_cell_index_device", _i32, [_vp, _vp]),
     ("pc_generate_device", _i32, [_i32, _u64, _c.c_int64, _u64, _u64, _vp, _vp]),
 ]
+
+
+class Geometry(ctypes.Structure):
+    """pc_geometry of include/paircount.h: domain origin, cell edge, cells per axis, squared cutoff."""
+    _fields_ = [("origin", ctypes.c_double), ("cell", ctypes.c_double), ("ncell", ctypes.c_int32), ("d2max", ctypes.c_float)]
+
+    def __init__(self, origin=-10.0, cell=0.05, ncell=400, d2max=None, cutoff=None):
+        import numpy as np
+        if d2max is None:
+            d2max = 0.0025 if cutoff is None else float(np.float32(cutoff) * np.float32(cutoff))
+        super().__init__(float(origin), float(cell), int(ncell), float(np.float32(d2max)))
 
 
 class PairCountError(RuntimeError):
@@ -147,11 +163,13 @@ class PairCounter:
     npairs = pc.finish()                            # flatten+count  (main.c:331-335)
     """
 
-    def __init__(self, device=0, expected_points=0, slab=None):
+    def __init__(self, device=0, expected_points=0, slab=None, geometry=None):
         self._h = ctypes.c_void_p()
         _check(lib().pc_create(ctypes.byref(self._h), int(device), int(expected_points)))
         if slab is not None:
             _check(lib().pc_set_slab(self._h, int(slab[0]), int(slab[1])))
+        if geometry is not None:
+            _check(lib().pc_set_geometry(self._h, ctypes.byref(geometry)))
 
     def append(self, xyz):
         a, p, n = _host_ptr(xyz)
@@ -234,11 +252,15 @@ class DeviceStages:
             raise PairCountError(-1, "n=%d exceeds DeviceStages capacity %d" % (n, self.capacity))
         return n
 
-    def cell_keys(self, xyz, keys=None):
+    def cell_keys(self, xyz, keys=None, geometry=None):
         n = self._n(xyz)
         if keys is None:
             keys = self.torch.empty(max(n, 1), dtype=self.torch.int32, device=self.device)
-        _check(lib().pc_cell_keys_device(xyz.data_ptr(), n, keys.data_ptr(), self.status.data_ptr(), self._stream()))
+        if geometry is None:
+            _check(lib().pc_cell_keys_device(xyz.data_ptr(), n, keys.data_ptr(), self.status.data_ptr(), self._stream()))
+        else:
+            _check(lib().pc_cell_keys_geometry_device(ctypes.byref(geometry), xyz.data_ptr(), n, keys.data_ptr(),
+                                                      self.status.data_ptr(), self._stream()))
         return keys[:n]
 
     def bin(self, xyz):
@@ -259,12 +281,18 @@ class DeviceStages:
         _check(lib().pc_count_tests_device(self.table.data_ptr(), x_lo, x_hi,
                                            self.result.data_ptr() + 8, self._stream()))
 
-    def count_pairs(self, xyz, x_lo=0, x_hi=PC_NLAYERS):
+    def count_pairs(self, xyz, x_lo=0, x_hi=PC_NLAYERS, geometry=None):
         """Whole hot path, asynchronous; the count lands in self.result[0]."""
         n = self._n(xyz)
-        _check(lib().pc_count_pairs_device(xyz.data_ptr(), n, x_lo, x_hi, self.sorted.data_ptr(),
-                                           self.table.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
-                                           self.result.data_ptr(), self.status.data_ptr(), self._stream()))
+        if geometry is None:
+            _check(lib().pc_count_pairs_device(xyz.data_ptr(), n, x_lo, x_hi, self.sorted.data_ptr(),
+                                               self.table.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
+                                               self.result.data_ptr(), self.status.data_ptr(), self._stream()))
+        else:
+            _check(lib().pc_count_pairs_geometry_device(ctypes.byref(geometry), xyz.data_ptr(), n, x_lo, x_hi,
+                                                        self.sorted.data_ptr(), self.table.data_ptr(), self.ws.data_ptr(),
+                                                        self.ws_bytes, self.result.data_ptr(), self.status.data_ptr(),
+                                                        self._stream()))
         return n
 
     def pairs(self):

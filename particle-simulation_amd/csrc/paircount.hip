@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <pthread.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -41,6 +42,76 @@ static int pc_fail(int code, const char *fmt, ...)
 
 extern "C" const char *pc_last_error(void) { return g_err; }
 extern "C" const char *pc_version(void) { return "1.0 gfx950"; }
+
+// ---------------------------------------------------------------- geometry --
+// The geometry the kernels of the calling thread's current entry point run with.  The
+// classic entry points leave it at the reference's constants; the *_geometry entry
+// points and contexts with pc_set_geometry install theirs for the duration of the call
+// (entry points only enqueue work, so a thread-local "current" value is enough).
+static pc_geom geom_default()
+{
+    pc_geom g;
+    g.add = 10.0;            // f - (-10.)            main.c:134
+    g.cell = 0.05;           // BBSIZE                main.c:30
+    g.addf = 10.0f;
+    g.invf = 20.0f;
+    g.hi = 400.5f;
+    g.ncell = PC_NLAYERS;
+    g.d2max = 0.0025f;       // (double)d2 <= 0.0025  main.c:165, see pc_hit
+    return g;
+}
+static thread_local pc_geom t_geo = geom_default();
+struct geo_scope {
+    pc_geom saved;
+    explicit geo_scope(const pc_geom &g) : saved(t_geo) { t_geo = g; }
+    ~geo_scope() { t_geo = saved; }
+};
+
+extern "C" int pc_geometry_default(pc_geometry *g)
+{
+    if (!g) return pc_fail(PC_ERR_ARG, "pc_geometry_default: null pointer");
+    g->origin = -10.0;
+    g->cell = 0.05;
+    g->ncell = PC_NLAYERS;
+    g->d2max = 0.0025f;
+    return PC_OK;
+}
+
+// Checks a caller's geometry and derives the kernels' form of it.
+static int make_geom(const pc_geometry *in, pc_geom *out)
+{
+    if (!in) return pc_fail(PC_ERR_ARG, "null geometry");
+    const double origin = in->origin, cell = in->cell;
+    if (!(cell > 0.0) || !(cell < 1e30) || !(origin > -1e30 && origin < 1e30))
+        return pc_fail(PC_ERR_ARG, "geometry: origin %g / cell edge %g not usable", origin, cell);
+    if (in->ncell < 1 || in->ncell > PC_NLAYERS)
+        return pc_fail(PC_ERR_ARG, "geometry: %d cells per axis not in [1,%d]", in->ncell, PC_NLAYERS);
+    if (!(in->d2max > 0.0f) || !(in->d2max < 1e30f))
+        return pc_fail(PC_ERR_ARG, "geometry: squared cutoff %g not positive and finite", (double)in->d2max);
+    pc_geom g = geom_default();
+    const bool is_default = origin == -10.0 && cell == 0.05 && in->d2max == 0.0025f;
+    // The stencil of 13 neighbour cells (main.c:195-209) finds every pair only if the cutoff does not exceed the
+    // cell edge, and the merged-window pair test also needs points two cells apart to FAIL the predicate with
+    // every rounding accounted for.  For the reference's constants that is shown bit by bit (pc_count_merge.h);
+    // any other pair of values must leave a margin that dwarfs the binary32 roundings.
+    if (!is_default && !((double)in->d2max <= cell * cell * (1.0 - 1e-5)))
+        return pc_fail(PC_ERR_ARG, "geometry: squared cutoff %.9g exceeds cell edge squared %.9g less a 1e-5 margin",
+                       (double)in->d2max, cell * cell);
+    g.add = -origin;
+    g.cell = cell;
+    g.ncell = in->ncell;
+    g.d2max = in->d2max;
+    g.addf = (float)g.add;
+    g.invf = (float)(1.0 / cell);
+    // error budget of the binary32 shortcut in cells (see pc_cell_index): representation of add and 1/cell,
+    // rounding of the sum and of the product; the shortcut is trusted 1e-3 cells away from a boundary
+    const double span = fabs(g.add) + (in->ncell + 1) * cell;                 // largest |f + add| of interest
+    const double err = (fabs(g.add - (double)g.addf) + ldexp(span, -24)) / cell
+                     + (in->ncell + 1) * (fabs(1.0 / cell - (double)g.invf) * cell + ldexp(1.0, -23));
+    g.hi = err < 2.5e-4 ? (float)in->ncell + 0.5f : 0.0f;                     // 0: every point takes the exact formula
+    *out = g;
+    return PC_OK;
+}
 
 // ---------------------------------------------------------------- variants --
 // Process-wide measurement knobs (pc_set_variant): atomics, so that a host thread changing one while
@@ -247,14 +318,14 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
     PC_HIP(hipMemsetAsync(w.layer_count, 0, (PC_L_NREP * PC_L_BINS + PC_L_NREP * PC_L_PSTRIDE + 8) * sizeof(uint32_t), s));
     const int tiles = (int)((n + PC_L_TILE - 1) / PC_L_TILE);
     if (n) PC_LAUNCH("pc_l1_hist_x", pc_l1_hist_x, dim3(grid_for(n, PC_L_TILE, 2048)), dim3(PC_L_TPB), s,
-                     d_xyz, n, w.layer_count, d_status);
+                     d_xyz, n, w.layer_count, d_status, t_geo);
     PC_LAUNCH("pc_l2_scan_x", pc_l2_scan_x, dim3(1), dim3(512), s, w.layer_count, w.layer_start, w.layer_cursor,
               w.layer_tile, w.tile_layer);
     if (n) {
         PC_LAUNCH("pc_l3_partition_x", pc_l36_partition<0>, dim3(tiles), dim3(PC_L_PTPB), s, d_xyz, n, d_sorted,
-                  w.layer_start, w.layer_tile, w.tile_layer, w.layer_cursor, w.ycell);
+                  w.layer_start, w.layer_tile, w.tile_layer, w.layer_cursor, w.ycell, t_geo);
         PC_LAUNCH("pc_l4_hist_y", pc_l4_hist_y, dim3(tiles + PC_NBB), dim3(PC_L_TPB), s, w.ycell, w.layer_start,
-                  w.layer_tile, w.tile_layer, w.pencil_count, d_status);
+                  w.layer_tile, w.tile_layer, w.pencil_count, d_status, t_geo);
     }
     // sparse inputs (at most half the small capacity per occupied pencil on average) take the low-LDS form of L7
     const uint64_t occupied_pencils = (uint64_t)(layer_hi < PC_NLAYERS ? layer_hi - layer_lo + 1 : PC_NLAYERS - layer_lo) * PC_NLAYERS;
@@ -263,32 +334,32 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
               w.pencil_start, w.pencil_cursor, (uint32_t)(sparse ? PC_L7_CAP_SPARSE : PC_L7_CAP), w.big_count, w.big_list);
     if (n)
         PC_LAUNCH("pc_l6_partition_y", pc_l36_partition<1>, dim3(tiles + PC_NBB), dim3(PC_L_PTPB), s, d_sorted, n,
-                  w.tmp, w.layer_start, w.layer_tile, w.tile_layer, w.pencil_cursor, w.ycell);
+                  w.tmp, w.layer_start, w.layer_tile, w.tile_layer, w.pencil_cursor, w.ycell, t_geo);
     const uint32_t first_pencil = (uint32_t)layer_lo * PC_NBB, end_pencil = (uint32_t)(layer_hi + 1) * PC_NBB;
     const dim3 l7_grid((end_pencil - first_pencil + PC_L7_WAVES - 1) / PC_L7_WAVES);
     if (sparse)
         PC_LAUNCH("pc_l7_sort_pencils", pc_l7_sort_pencils<PC_L7_CAP_SPARSE>, l7_grid, dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted,
-                  w.pencil_start, table, first_pencil, end_pencil, d_status);
+                  w.pencil_start, table, first_pencil, end_pencil, d_status, t_geo);
     else
         PC_LAUNCH("pc_l7_sort_pencils", pc_l7_sort_pencils<PC_L7_CAP>, l7_grid, dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted,
-                  w.pencil_start, table, first_pencil, end_pencil, d_status);
+                  w.pencil_start, table, first_pencil, end_pencil, d_status, t_geo);
     // pencils too big for a wave (listed by L5): one workgroup each, fixed grids walk the list, one per size class
     auto small = pc_l7b_sort_big_pencils<PC_L7B_CAP_SMALL, PC_L7B_TPB_SMALL>;
     auto large = pc_l7b_sort_big_pencils<PC_L7B_CAP_LARGE, PC_L7B_TPB_LARGE>;
     static int small_grid, large_grid;            // (one device model per process is assumed for these two)
     PC_LAUNCH("pc_l7b_sort_big_pencils", small, dim3(resident_blocks(small, PC_L7B_TPB_SMALL, &small_grid)), dim3(PC_L7B_TPB_SMALL), s, w.tmp, d_sorted, w.pencil_start, table,
               w.big_count, w.big_list, first_pencil, end_pencil, 0u, (uint32_t)PC_L7B_CAP_SMALL,
-              (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, d_status);
+              (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, d_status, t_geo);
     PC_LAUNCH("pc_l7b_sort_big_pencils", large, dim3(resident_blocks(large, PC_L7B_TPB_LARGE, &large_grid)), dim3(PC_L7B_TPB_LARGE), s, w.tmp, d_sorted, w.pencil_start, table,
               w.big_count, w.big_list, first_pencil, end_pencil, (uint32_t)PC_L7B_CAP_SMALL, (uint32_t)PC_L7B_CAP_LARGE,
-              w.big_count + 1, w.huge_list, w.huge_count, d_status);
+              w.big_count + 1, w.huge_list, w.huge_count, d_status, t_geo);
     // pencils beyond a workgroup's capacity (listed just now): tile-parallel histogram, scan, partition
     PC_LAUNCH("pc_l7h_hist", pc_l7h_hist, dim3(PC_L7H_GRID), dim3(PC_L_TPB), s, w.tmp, w.pencil_start, w.big_count + 1,
-              w.huge_list, w.huge_count, d_status);
+              w.huge_list, w.huge_count, d_status, t_geo);
     PC_LAUNCH("pc_l7h_scan", pc_l7h_scan, dim3(256), dim3(64), s, w.pencil_start, w.big_count + 1, w.huge_list,
               w.huge_count, w.huge_cursor, table);
     PC_LAUNCH("pc_l7h_partition", pc_l7h_partition, dim3(PC_L7H_GRID), dim3(PC_L_PTPB), s, w.tmp, d_sorted, w.pencil_start,
-              w.big_count + 1, w.huge_list, w.huge_cursor);
+              w.big_count + 1, w.huge_list, w.huge_cursor, t_geo);
     PC_HIP(hipGetLastError());
     return PC_OK;
 }
@@ -318,9 +389,28 @@ extern "C" int pc_selfcheck_cell_index_device(uint64_t *d_mismatches, void *stre
 {
     if (!d_mismatches) return pc_fail(PC_ERR_ARG, "pc_selfcheck_cell_index_device: null pointer");
     PC_LAUNCH("pc_selfcheck_cell_index", pc_selfcheck_cell_index, dim3(65536), dim3(256), (hipStream_t)stream,
-              (unsigned long long *)d_mismatches);
+              (unsigned long long *)d_mismatches, t_geo);
     PC_HIP(hipGetLastError());
     return PC_OK;
+}
+
+extern "C" int pc_selfcheck_cell_index_geometry_device(const pc_geometry *g, uint64_t *d_mismatches, void *stream)
+{
+    pc_geom geo;
+    int rc = make_geom(g, &geo);
+    if (rc) return rc;
+    geo_scope scope(geo);
+    return pc_selfcheck_cell_index_device(d_mismatches, stream);
+}
+
+extern "C" int pc_cell_keys_geometry_device(const pc_geometry *g, const float *d_xyz, uint64_t n, uint32_t *d_keys,
+                                            int32_t *d_status, void *stream)
+{
+    pc_geom geo;
+    int rc = make_geom(g, &geo);
+    if (rc) return rc;
+    geo_scope scope(geo);
+    return pc_cell_keys_device(d_xyz, n, d_keys, d_status, stream);
 }
 
 extern "C" int pc_cell_keys_device(const float *d_xyz, uint64_t n, uint32_t *d_keys,
@@ -331,7 +421,7 @@ extern "C" int pc_cell_keys_device(const float *d_xyz, uint64_t n, uint32_t *d_k
     if (n > PC_MAX_POINTS) return pc_fail(PC_ERR_ARG, "pc_cell_keys_device: n too large");
     if (n == 0) return PC_OK;
     PC_LAUNCH("pc_keys_only", pc_keys_only, dim3(grid_for(n, 256, 8192)), dim3(256), (hipStream_t)stream,
-                       d_xyz, n, d_keys, d_status);
+                       d_xyz, n, d_keys, d_status, t_geo);
     PC_HIP(hipGetLastError());
     return PC_OK;
 }
@@ -371,7 +461,7 @@ static int bin_layers(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
     PC_HIP(hipMemsetAsync(d_cell_start, 0, m * sizeof(uint32_t), s));
     if (n)
         PC_LAUNCH("pc_a1_keys_hist", pc_a1_keys_hist, dim3(grid_for(n, 256, 8192)), dim3(256), s, d_xyz, n, keys,
-                           d_cell_start, d_status);
+                           d_cell_start, d_status, t_geo);
     PC_LAUNCH("pc_a2_scan_reduce", pc_a2_scan_reduce, dim3(ntiles), dim3(PC_SCAN_TPB), s, d_cell_start, m, sums);
     PC_LAUNCH("pc_a2_scan_spine", pc_a2_scan_spine, dim3(1), dim3(PC_SCAN_TPB), s, sums, ntiles);
     PC_LAUNCH("pc_a2_scan_apply", pc_a2_scan_apply, dim3(ntiles), dim3(PC_SCAN_TPB), s, d_cell_start, m, sums);
@@ -440,7 +530,7 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
     if (variant == 0) {
         uint32_t c_lo = (uint32_t)x_lo * PC_NBB2, c_hi = (uint32_t)x_hi * PC_NBB2;
         PC_LAUNCH("pc_c0_count_global", pc_c0_count_global, dim3(grid_for(n, 256, 4096)), dim3(256), (hipStream_t)stream, d_sorted_xyz, d_cell_start, c_lo, c_hi,
-                           (unsigned long long *)d_npairs);
+                           (unsigned long long *)d_npairs, t_geo);
     } else if (variant == 3 || variant == 5) {
         // persistent: one resident set of waves, never more waves than pencils;
         // the eight work counters are zeroed on the stream ahead of the launch
@@ -489,34 +579,34 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
             const int grid5 = ((r5 < most ? r5 : most) + 7) / 8 * 8;
             PC_LAUNCH("pc_c5_count_merged", pc_c5_count_merged, dim3(grid5), dim3(64), (hipStream_t)stream,
                       d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, PC_GATE_IF_EVEN, gate_limit,
-                      (unsigned long long *)d_npairs);
+                      (unsigned long long *)d_npairs, t_geo);
         }
         const int grid = ((want < most ? want : most) + 7) / 8 * 8;
         if (variant == 5) {
             PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups<false>, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
                       d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap, PC_GATE_IF_EVEN, gate_limit,
-                      (unsigned long long *)d_npairs);
+                      (unsigned long long *)d_npairs, t_geo.d2max);
             PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups<true>, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
                       d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap, PC_GATE_IF_CLUSTERED, gate_limit,
-                      (unsigned long long *)d_npairs);
+                      (unsigned long long *)d_npairs, t_geo.d2max);
         } else
             PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups<true>, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
                       d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap, PC_GATE_ALWAYS, 0u,
-                      (unsigned long long *)d_npairs);
+                      (unsigned long long *)d_npairs, t_geo.d2max);
         // the home particles of over-full cells that the waves listed instead of processing (normally none:
         // the workgroups then return at once)
         PC_LAUNCH("pc_c3_heavy", pc_c3_heavy, dim3(resident >= 2048 ? 2048 : resident), dim3(PC_HV_TPB), (hipStream_t)stream,
-                  d_sorted_xyz, d_cell_start, queue, heavy_cap, (unsigned long long *)d_npairs);
+                  d_sorted_xyz, d_cell_start, queue, heavy_cap, (unsigned long long *)d_npairs, t_geo.d2max);
     } else if (variant == 2) {
         const int grid = 8 * (x_hi - x_lo) * PC_W_WG_PER_BAND;
         PC_LAUNCH("pc_c2_count_waves", pc_c2_count_waves, dim3(grid), dim3(PC_W_WAVES * 64), (hipStream_t)stream,
-                  d_sorted_xyz, d_cell_start, x_lo, x_hi, (unsigned long long *)d_npairs);
+                  d_sorted_xyz, d_cell_start, x_lo, x_hi, (unsigned long long *)d_npairs, t_geo);
     } else {
         // 8 XCD groups x layers x (largest band of strips any group owns)
         const int band = (PC_T_NS + 7) / 8;
         const int grid = 8 * (x_hi - x_lo) * band;
         PC_LAUNCH("pc_c1_count_tiles", pc_c1_count_tiles, dim3(grid), dim3(PC_T_TPB), (hipStream_t)stream,
-                           d_sorted_xyz, d_cell_start, x_lo, x_hi, (unsigned long long *)d_npairs);
+                           d_sorted_xyz, d_cell_start, x_lo, x_hi, (unsigned long long *)d_npairs, t_geo);
     }
     PC_HIP(hipGetLastError());
     return PC_OK;
@@ -550,6 +640,19 @@ extern "C" int pc_count_pairs_device(const float *d_xyz, uint64_t n, int x_lo, i
     if (rc) return rc;
     PC_HIP(hipMemsetAsync(d_npairs, 0, sizeof(uint64_t), (hipStream_t)stream));
     return pc_count_sorted_device(d_sorted_xyz, d_cell_start, n, x_lo, x_hi, d_npairs, stream);
+}
+
+extern "C" int pc_count_pairs_geometry_device(const pc_geometry *g, const float *d_xyz, uint64_t n, int x_lo, int x_hi,
+                                              float *d_sorted_xyz, uint32_t *d_cell_start,
+                                              void *d_workspace, size_t workspace_bytes,
+                                              uint64_t *d_npairs, int32_t *d_status, void *stream)
+{
+    pc_geom geo;
+    int rc = make_geom(g, &geo);
+    if (rc) return rc;
+    geo_scope scope(geo);
+    return pc_count_pairs_device(d_xyz, n, x_lo, x_hi, d_sorted_xyz, d_cell_start, d_workspace, workspace_bytes, d_npairs,
+                                 d_status, stream);
 }
 
 // ------------------------------------------------- allocation-free entry point --
@@ -607,6 +710,7 @@ struct pc_context {
     pthread_mutex_t reserve;    // serialises slot reservation
     float *d_xyz;
     uint64_t cap, size;
+    pc_geom geo;                // geometry of the run (pc_set_geometry; the reference's by default)
     int finished;               // appends are closed (set by the first pc_finish)
     int done;                   // pc_finish has run to its end: finish_rc, npairs, ntests, ms are final
     int finish_rc;              // what that pc_finish returned; later calls return it again
@@ -631,6 +735,7 @@ extern "C" int pc_create(pc_context **out, int device, uint64_t expected_points)
     c->device = device;
     c->x_lo = 0;
     c->x_hi = PC_NLAYERS;
+    c->geo = geom_default();
     c->cap = expected_points ? expected_points : (1u << 20);
     pthread_rwlock_init(&c->lock, NULL);
     pthread_mutex_init(&c->reserve, NULL);
@@ -652,6 +757,19 @@ extern "C" int pc_set_slab(pc_context *c, int x_lo, int x_hi)
     c->x_lo = x_lo;
     c->x_hi = x_hi;
     return PC_OK;
+}
+
+extern "C" int pc_set_geometry(pc_context *c, const pc_geometry *g)
+{
+    if (!c) return pc_fail(PC_ERR_ARG, "pc_set_geometry: null context");
+    pc_geom geo;
+    int rc = make_geom(g, &geo);
+    if (rc) return rc;
+    pthread_rwlock_wrlock(&c->lock);
+    if (c->finished) rc = pc_fail(PC_ERR_STATE, "pc_set_geometry after pc_finish");
+    else c->geo = geo;
+    pthread_rwlock_unlock(&c->lock);
+    return rc;
 }
 
 // Reserve [off, off+n) in the device array, growing it if needed; returns with
@@ -801,6 +919,7 @@ static int finish_work(pc_context *c)
 {
     if (c->append_rc) return pc_fail(c->append_rc, "an earlier append failed (%s): the context holds no usable point set", c->append_msg);
     PC_HIP(hipSetDevice(c->device));
+    geo_scope scope(c->geo);
     const uint64_t n = c->size;
     finish_bufs b;
     const size_t wsb = pc_workspace_bytes(n);

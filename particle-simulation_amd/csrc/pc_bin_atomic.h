@@ -21,14 +21,14 @@
 // replaces main.c:134-137 + the counting side of hashmap.h:94-135
 __global__ void __launch_bounds__(256)
 pc_a1_keys_hist(const float *__restrict__ xyz, uint64_t n, uint32_t *__restrict__ keys,
-                uint32_t *__restrict__ table, int32_t *__restrict__ status)
+                uint32_t *__restrict__ table, int32_t *__restrict__ status, const pc_geom geo)
 {
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     bool bad = false;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         float x = xyz[3 * p], y = xyz[3 * p + 1], z = xyz[3 * p + 2];
-        int i = pc_cell_index(x), j = pc_cell_index(y), k = pc_cell_index(z);
-        if (!pc_in_grid(i, j, k)) { bad = true; keys[p] = 0xFFFFFFFFu; continue; }
+        int i = pc_cell_index(x, geo), j = pc_cell_index(y, geo), k = pc_cell_index(z, geo);
+        if (!pc_in_grid(i, j, k, geo)) { bad = true; keys[p] = 0xFFFFFFFFu; continue; }
         uint32_t key = pc_key(i, j, k);
         keys[p] = key;
         atomicAdd(&table[key + 2], 1u);
@@ -38,14 +38,14 @@ pc_a1_keys_hist(const float *__restrict__ xyz, uint64_t n, uint32_t *__restrict_
 
 // every float bit pattern: shortcut index against the reference expression
 __global__ void __launch_bounds__(256)
-pc_selfcheck_cell_index(unsigned long long *__restrict__ mismatches)
+pc_selfcheck_cell_index(unsigned long long *__restrict__ mismatches, const pc_geom geo)
 {
     unsigned int bad = 0;
     const uint32_t first = (blockIdx.x * 256u + threadIdx.x) * 256u;     // grid 65536 x 256 threads x 256 patterns = 2^32
     for (uint32_t q = 0; q < 256u; q++) {
         const float f = __uint_as_float(first + q);
         if (f != f) continue;                                          // NaN: the conversion to int is not defined by the reference
-        bad += pc_cell_index(f) != pc_cell_index_exact(f);
+        bad += pc_cell_index(f, geo) != pc_cell_index_exact(f, geo);
     }
     if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
@@ -53,14 +53,14 @@ pc_selfcheck_cell_index(unsigned long long *__restrict__ mismatches)
 // keys only (the stage entry point pc_cell_keys_device)
 __global__ void __launch_bounds__(256)
 pc_keys_only(const float *__restrict__ xyz, uint64_t n, uint32_t *__restrict__ keys,
-             int32_t *__restrict__ status)
+             int32_t *__restrict__ status, const pc_geom geo)
 {
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     bool bad = false;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         float x = xyz[3 * p], y = xyz[3 * p + 1], z = xyz[3 * p + 2];
-        int i = pc_cell_index(x), j = pc_cell_index(y), k = pc_cell_index(z);
-        if (!pc_in_grid(i, j, k)) bad = true;
+        int i = pc_cell_index(x, geo), j = pc_cell_index(y, geo), k = pc_cell_index(z, geo);
+        if (!pc_in_grid(i, j, k, geo)) bad = true;
         keys[p] = (uint32_t)(i * PC_NBB2 + j * PC_NBB + k);   // INDEX(), main.c:32
     }
     if (bad) atomicOr(status, 1);

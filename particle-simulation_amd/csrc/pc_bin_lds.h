@@ -63,7 +63,7 @@ struct pc_lds_ws {
 // tile a workgroup visits has the same replica.
 __global__ void __launch_bounds__(PC_L_TPB)
 pc_l1_hist_x(const float *__restrict__ xyz, uint64_t n, uint32_t *__restrict__ layer_count,
-             int32_t *__restrict__ status)
+             int32_t *__restrict__ status, const pc_geom geo)
 {
     __shared__ uint32_t h[PC_L_BINS];
     for (int b = threadIdx.x; b < PC_L_BINS; b += PC_L_TPB) h[b] = 0;
@@ -80,8 +80,8 @@ pc_l1_hist_x(const float *__restrict__ xyz, uint64_t n, uint32_t *__restrict__ l
 #pragma unroll
         for (int j = 0; j < PC_L_PPT; j++) {
             if ((uint32_t)(threadIdx.x + j * PC_L_TPB) < cnt) {
-                const int i = pc_cell_index(xs[j]);
-                if ((unsigned)i < 400u) atomicAdd(&h[i], 1u);
+                const int i = pc_cell_index(xs[j], geo);
+                if ((unsigned)i < (unsigned)geo.ncell) atomicAdd(&h[i], 1u);
                 else bad = true;
             }
         }
@@ -137,7 +137,7 @@ pc_l2_scan_x(const uint32_t *__restrict__ layer_count, uint32_t *__restrict__ la
 __global__ void __launch_bounds__(PC_L_TPB)
 pc_l4_hist_y(const uint16_t *__restrict__ ycell, const uint32_t *__restrict__ layer_start,
              const uint32_t *__restrict__ layer_tile, const uint32_t *__restrict__ tile_layer,
-             uint32_t *__restrict__ pencil_count, int32_t *__restrict__ status)
+             uint32_t *__restrict__ pencil_count, int32_t *__restrict__ status, const pc_geom geo)
 {
     __shared__ uint32_t h[PC_L_BINS];
     if (blockIdx.x >= layer_tile[PC_NBB]) return;
@@ -155,7 +155,7 @@ pc_l4_hist_y(const uint16_t *__restrict__ ycell, const uint32_t *__restrict__ la
 #pragma unroll
     for (int j = 0; j < PC_L_PPT; j++) {
         if ((uint32_t)(threadIdx.x + j * PC_L_TPB) < cnt) {
-            if (ys[j] < 400u) atomicAdd(&h[ys[j]], 1u);
+            if (ys[j] < (unsigned)geo.ncell) atomicAdd(&h[ys[j]], 1u);
             else bad = true;
         }
     }
@@ -212,7 +212,7 @@ template <int LEVEL>
 __global__ void __launch_bounds__(PC_L_PTPB)
 pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ dst,
                  const uint32_t *__restrict__ layer_start, const uint32_t *__restrict__ layer_tile,
-                 const uint32_t *__restrict__ tile_layer, uint32_t *__restrict__ cursor, uint16_t *__restrict__ ycell)
+                 const uint32_t *__restrict__ tile_layer, uint32_t *__restrict__ cursor, uint16_t *__restrict__ ycell, const pc_geom geo)
 {
     __shared__ float buf[PC_L_TILE * 3];              // the tile sorted by bin
     __shared__ uint16_t bin_of[PC_L_TILE];
@@ -254,11 +254,11 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
         tag[j] = 0xFFFFFFFFu;
         if ((uint32_t)(tid + j * PC_L_PTPB) < cnt) {
             if (LEVEL == 0) {
-                const int cy = pc_cell_index(pt[j].y);
-                yc[j] = (unsigned)cy < 400u ? (uint32_t)cy : 0xFFFFu;
+                const int cy = pc_cell_index(pt[j].y, geo);
+                yc[j] = (unsigned)cy < (unsigned)geo.ncell ? (uint32_t)cy : 0xFFFFu;
             }
-            const uint32_t b = (uint32_t)pc_cell_index(LEVEL == 0 ? pt[j].x : pt[j].y);
-            if (b < 400u) tag[j] = b | (atomicAdd(&hist[b], 1u) << 10);
+            const uint32_t b = (uint32_t)pc_cell_index(LEVEL == 0 ? pt[j].x : pt[j].y, geo);
+            if (b < (unsigned)geo.ncell) tag[j] = b | (atomicAdd(&hist[b], 1u) << 10);
         }
     }
     __syncthreads();
@@ -342,7 +342,7 @@ template <int CAP>
 __global__ void __launch_bounds__(PC_L7_WAVES * 64)
 pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
                    const uint32_t *__restrict__ pencil_start, uint32_t *__restrict__ table,
-                   uint32_t first_pencil, uint32_t end_pencil, int32_t *__restrict__ status)
+                   uint32_t first_pencil, uint32_t end_pencil, int32_t *__restrict__ status, const pc_geom geo)
 {
     __shared__ uint32_t hist_all[PC_L7_WAVES][PC_L_BINS];
     constexpr int PPL = CAP / 64;                      // points per lane
@@ -377,8 +377,8 @@ pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
         for (int j = 0; j < PPL; j++) {
             tag[j] = 0xFFFFFFFFu;
             if (j < rounds && lane + 64u * j < n) {
-                const int k = pc_cell_index(pt[j].z);
-                if ((unsigned)k < 400u) tag[j] = (uint32_t)k | (atomicAdd(&hist[k], 1u) << 10);
+                const int k = pc_cell_index(pt[j].z, geo);
+                if ((unsigned)k < (unsigned)geo.ncell) tag[j] = (uint32_t)k | (atomicAdd(&hist[k], 1u) << 10);
                 else bad = true;
             }
         }
@@ -434,7 +434,7 @@ pc_l7b_sort_big_pencils(const float *__restrict__ src, float *__restrict__ dst,
                         const uint32_t *__restrict__ big_count, const uint32_t *__restrict__ big_list,
                         uint32_t first_pencil, uint32_t end_pencil, uint32_t n_above, uint32_t n_upto,
                         uint32_t *__restrict__ huge_n, uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count,
-                        int32_t *__restrict__ status)
+                        int32_t *__restrict__ status, const pc_geom geo)
 {
     constexpr int PC_L7B_PPT = PC_L7B_CAP / PC_L7B_TPB;
     __shared__ uint32_t hist[PC_L_BINS];
@@ -473,8 +473,8 @@ pc_l7b_sort_big_pencils(const float *__restrict__ src, float *__restrict__ dst,
             for (int q = 0; q < PC_L7B_PPT; q++) {
                 tag[q] = 0xFFFFFFFFu;
                 if ((uint32_t)(tid + q * PC_L7B_TPB) < n) {
-                    const int k = pc_cell_index(pt[q].z);
-                    if ((unsigned)k < 400u) tag[q] = (uint32_t)k | (atomicAdd(&hist[k], 1u) << 10);
+                    const int k = pc_cell_index(pt[q].z, geo);
+                    if ((unsigned)k < (unsigned)geo.ncell) tag[q] = (uint32_t)k | (atomicAdd(&hist[k], 1u) << 10);
                     else bad = true;
                 }
             }
@@ -515,7 +515,7 @@ __device__ __forceinline__ uint32_t pc_l7h_first_tile(uint32_t h)
 
 __global__ void __launch_bounds__(PC_L_TPB)
 pc_l7h_hist(const float *__restrict__ src, const uint32_t *__restrict__ pencil_start, const uint32_t *__restrict__ huge_n,
-            const uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count, int32_t *__restrict__ status)
+            const uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count, int32_t *__restrict__ status, const pc_geom geo)
 {
     __shared__ uint32_t h_lds[PC_L_BINS];
     const uint32_t entries = *huge_n;
@@ -536,8 +536,8 @@ pc_l7h_hist(const float *__restrict__ src, const uint32_t *__restrict__ pencil_s
 #pragma unroll
             for (int j = 0; j < PC_L_PPT; j++) {
                 if ((uint32_t)(threadIdx.x + j * PC_L_TPB) < cnt) {
-                    const int k = pc_cell_index(zs[j]);
-                    if ((unsigned)k < 400u) atomicAdd(&h_lds[k], 1u);
+                    const int k = pc_cell_index(zs[j], geo);
+                    if ((unsigned)k < (unsigned)geo.ncell) atomicAdd(&h_lds[k], 1u);
                     else bad = true;
                 }
             }
@@ -573,7 +573,7 @@ pc_l7h_scan(const uint32_t *__restrict__ pencil_start, const uint32_t *__restric
 __global__ void __launch_bounds__(PC_L_PTPB)
 pc_l7h_partition(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ pencil_start,
                  const uint32_t *__restrict__ huge_n, const uint32_t *__restrict__ huge_list,
-                 uint32_t *__restrict__ huge_cursor)
+                 uint32_t *__restrict__ huge_cursor, const pc_geom geo)
 {
     __shared__ float buf[PC_L_TILE * 3];              // the tile sorted by cell
     __shared__ uint16_t bin_of[PC_L_TILE];
@@ -599,8 +599,8 @@ pc_l7h_partition(const float *__restrict__ src, float *__restrict__ dst, const u
             for (int j = 0; j < PC_L_PPPT; j++) {
                 tag[j] = 0xFFFFFFFFu;
                 if ((uint32_t)(tid + j * PC_L_PTPB) < cnt) {
-                    const uint32_t b = (uint32_t)pc_cell_index(pt[j].z);
-                    if (b < 400u) tag[j] = b | (atomicAdd(&hist[b], 1u) << 10);
+                    const uint32_t b = (uint32_t)pc_cell_index(pt[j].z, geo);
+                    if (b < (unsigned)geo.ncell) tag[j] = b | (atomicAdd(&hist[b], 1u) << 10);
                 }
             }
             __syncthreads();

@@ -18,14 +18,14 @@
 // Slots the binning left unwritten (it drops out-of-domain points and flags the status
 // word) still hold whatever the scratch use of the array put there: a point outside
 // the grid is never a home particle, and its key must not index the table.
-__device__ __forceinline__ uint32_t pc_count_one_home(const float *__restrict__ pts, const uint32_t *__restrict__ T, uint32_t p)
+__device__ __forceinline__ uint32_t pc_count_one_home(const float *__restrict__ pts, const uint32_t *__restrict__ T, uint32_t p, const pc_geom &geo)
 {
     struct pt3 { float x, y, z; };                 // one 12-byte load per point
     const pt3 *P = reinterpret_cast<const pt3 *>(pts);
     const pt3 me = P[p];
     const float x = me.x, y = me.y, z = me.z;
-    const int ci = pc_cell_index(x), cj = pc_cell_index(y), ck = pc_cell_index(z);
-    if (!pc_in_grid(ci, cj, ck)) return 0;
+    const int ci = pc_cell_index(x, geo), cj = pc_cell_index(y, geo), ck = pc_cell_index(z, geo);
+    if (!pc_in_grid(ci, cj, ck, geo)) return 0;
     const uint32_t c = pc_key(ci, cj, ck);
     uint32_t cnt = 0;
     // the five candidate ranges: same cell (later slots) with cell c+1 = slots (p, T[c+2]), then the
@@ -49,7 +49,7 @@ __device__ __forceinline__ uint32_t pc_count_one_home(const float *__restrict__ 
             const v2f cx = {v0.x, v1.x}, cy = {v0.y, v1.y}, cz = {v0.z, v1.z};
             const v2f dx = ax - cx, dy = ay - cy, dz = az - cz;
             const v2f sq = (dx * dx + dy * dy) + dz * dz;            // unfused: see the build flags
-            cnt += (sq.x <= 0.0025f) + ((sq.y <= 0.0025f) & (q + 1 < hi[r]));
+            cnt += (sq.x <= geo.d2max) + ((sq.y <= geo.d2max) & (q + 1 < hi[r]));
         }
     }
     return cnt;
@@ -58,13 +58,13 @@ __device__ __forceinline__ uint32_t pc_count_one_home(const float *__restrict__ 
 __global__ void __launch_bounds__(256)
 pc_c0_count_global(const float *__restrict__ pts, const uint32_t *__restrict__ T,
                    uint32_t c_lo, uint32_t c_hi,   // home keys [c_lo, c_hi)
-                   unsigned long long *__restrict__ out)
+                   unsigned long long *__restrict__ out, const pc_geom geo)
 {
     unsigned long long acc = 0;
     const uint32_t first = T[c_lo], last = T[c_hi];   // their slots in sorted order
     uint32_t stride = gridDim.x * blockDim.x;
     for (uint64_t p64 = (uint64_t)first + blockIdx.x * blockDim.x + threadIdx.x; p64 < last; p64 += stride)
-        acc += pc_count_one_home(pts, T, (uint32_t)p64);
+        acc += pc_count_one_home(pts, T, (uint32_t)p64, geo);
     pc_block_add_u64<4>(acc, out);
 }
 

@@ -174,7 +174,7 @@ __device__ __forceinline__ uint32_t pc_from_lane_above(uint32_t v)      // lane 
 // are padded with a never-matching point), so a pair is one aligned 8-byte LDS
 // read and is live or dead as a whole.
 template <int G, int NP>
-__device__ __forceinline__ uint32_t pc_g_steps(const pc_group_lds &L, uint32_t h_first, uint32_t nh, int lane)
+__device__ __forceinline__ uint32_t pc_g_steps(const pc_group_lds &L, uint32_t h_first, uint32_t nh, int lane, float d2max)
 {
     constexpr int NP0 = G >= 4 ? 1 : 4 / G;             // same-pencil pairs per lane: at least 8 candidates per group
     uint32_t hits = 0;
@@ -209,8 +209,8 @@ __device__ __forceinline__ uint32_t pc_g_steps(const pc_group_lds &L, uint32_t h
 #pragma unroll
             for (int c = 0; c < NP; c++) {
                 const unsigned long long ok = __builtin_amdgcn_ballot_w64(rem > 2 * G * c);
-                hits += __popcll(__builtin_amdgcn_ballot_w64(sq[c].x <= 0.0025f) & ok)
-                      + __popcll(__builtin_amdgcn_ballot_w64(sq[c].y <= 0.0025f) & ok);
+                hits += __popcll(__builtin_amdgcn_ballot_w64(sq[c].x <= d2max) & ok)
+                      + __popcll(__builtin_amdgcn_ballot_w64(sq[c].y <= d2max) & ok);
             }
             rem -= 2 * G * NP;
             p += 2 * G * NP;
@@ -231,8 +231,8 @@ __device__ __forceinline__ uint32_t pc_g_steps(const pc_group_lds &L, uint32_t h
             }
 #pragma unroll
             for (int c = 0; c < NP0; c++) {
-                hits += __popcll(__builtin_amdgcn_ballot_w64(sq[c].x <= 0.0025f) & __builtin_amdgcn_ballot_w64(rem0 > 2 * G * c))
-                      + __popcll(__builtin_amdgcn_ballot_w64(sq[c].y <= 0.0025f) & __builtin_amdgcn_ballot_w64(rem0 > 2 * G * c + 1));
+                hits += __popcll(__builtin_amdgcn_ballot_w64(sq[c].x <= d2max) & __builtin_amdgcn_ballot_w64(rem0 > 2 * G * c))
+                      + __popcll(__builtin_amdgcn_ballot_w64(sq[c].y <= d2max) & __builtin_amdgcn_ballot_w64(rem0 > 2 * G * c + 1));
             }
             rem0 -= 2 * G * NP0;
             p0 += 2 * G * NP0;
@@ -248,18 +248,18 @@ __device__ __forceinline__ uint32_t pc_g_steps(const pc_group_lds &L, uint32_t h
 // times) as wide and as many fewer pairs per lane: the same candidates per pass
 // at half (a quarter of) the instructions.
 template <int G, int NP>
-__device__ __forceinline__ uint32_t pc_g_window(const pc_group_lds &L, uint32_t nh, int lane)
+__device__ __forceinline__ uint32_t pc_g_window(const pc_group_lds &L, uint32_t nh, int lane, float d2max)
 {
     constexpr uint32_t H = 64 / G;
     nh = __builtin_amdgcn_readfirstlane(nh);
     if constexpr (NP >= 4 && G <= 8) {
         const uint32_t rest = nh % H, whole = nh - rest;
-        uint32_t hits = pc_g_steps<G, NP>(L, 0, rest > H / 2 ? nh : whole, lane);
-        if (rest != 0 && rest <= H / 4) hits += pc_g_steps<4 * G, NP / 4>(L, whole, nh, lane);
-        else if (rest != 0 && rest <= H / 2) hits += pc_g_steps<2 * G, NP / 2>(L, whole, nh, lane);
+        uint32_t hits = pc_g_steps<G, NP>(L, 0, rest > H / 2 ? nh : whole, lane, d2max);
+        if (rest != 0 && rest <= H / 4) hits += pc_g_steps<4 * G, NP / 4>(L, whole, nh, lane, d2max);
+        else if (rest != 0 && rest <= H / 2) hits += pc_g_steps<2 * G, NP / 2>(L, whole, nh, lane, d2max);
         return hits;
     } else {
-        return pc_g_steps<G, NP>(L, 0, nh, lane);
+        return pc_g_steps<G, NP>(L, 0, nh, lane, d2max);
     }
 }
 
@@ -271,7 +271,7 @@ __device__ __forceinline__ uint32_t pc_g_window(const pc_group_lds &L, uint32_t 
 // meta.x & 0xFFFF (the "later slots of the same cell" rule of main.c:215-221).
 template <bool USE_LO, int PAIRS>
 __device__ __forceinline__ uint32_t pc_g_chunk(const pc_group_lds &L, uint32_t p0, uint32_t c_hi,
-                                               uint32_t h_lo, uint32_t h_hi, int lane)
+                                               uint32_t h_lo, uint32_t h_hi, int lane, float d2max)
 {
     uint32_t hits = 0;
     const uint32_t p = p0 + lane;
@@ -294,8 +294,8 @@ __device__ __forceinline__ uint32_t pc_g_chunk(const pc_group_lds &L, uint32_t p
         for (int c = 0; c < PAIRS; c++) {
             const pc_v2f dx = ax - x[c], dy = ay - y[c], dz = az - z[c];
             const pc_v2f sq = (dx * dx + dy * dy) + dz * dz;
-            unsigned long long b0 = __builtin_amdgcn_ballot_w64(sq.x <= 0.0025f) & ok[2 * c];
-            unsigned long long b1 = __builtin_amdgcn_ballot_w64(sq.y <= 0.0025f) & ok[2 * c + 1];
+            unsigned long long b0 = __builtin_amdgcn_ballot_w64(sq.x <= d2max) & ok[2 * c];
+            unsigned long long b1 = __builtin_amdgcn_ballot_w64(sq.y <= d2max) & ok[2 * c + 1];
             if (USE_LO) {
                 b0 &= __builtin_amdgcn_ballot_w64(p + 128 * c >= lo);
                 b1 &= __builtin_amdgcn_ballot_w64(p + 128 * c + 64 >= lo);
@@ -309,14 +309,14 @@ __device__ __forceinline__ uint32_t pc_g_chunk(const pc_group_lds &L, uint32_t p
 // candidates [c_lo, c_hi) in chunks of 256, the last one 128 wide if that is enough
 template <bool USE_LO>
 __device__ __forceinline__ uint32_t pc_g_block(const pc_group_lds &L, uint32_t c_lo, uint32_t c_hi,
-                                               uint32_t h_lo, uint32_t h_hi, int lane)
+                                               uint32_t h_lo, uint32_t h_hi, int lane, float d2max)
 {
     uint32_t hits = 0;
     c_lo = __builtin_amdgcn_readfirstlane(c_lo); c_hi = __builtin_amdgcn_readfirstlane(c_hi);
     h_lo = __builtin_amdgcn_readfirstlane(h_lo); h_hi = __builtin_amdgcn_readfirstlane(h_hi);
     uint32_t p0 = c_lo;
-    for (; p0 + 128 < c_hi; p0 += 256) hits += pc_g_chunk<USE_LO, 2>(L, p0, c_hi, h_lo, h_hi, lane);
-    if (p0 < c_hi) hits += pc_g_chunk<USE_LO, 1>(L, p0, c_hi, h_lo, h_hi, lane);
+    for (; p0 + 128 < c_hi; p0 += 256) hits += pc_g_chunk<USE_LO, 2>(L, p0, c_hi, h_lo, h_hi, lane, d2max);
+    if (p0 < c_hi) hits += pc_g_chunk<USE_LO, 1>(L, p0, c_hi, h_lo, h_hi, lane, d2max);
     return hits;
 }
 
@@ -385,7 +385,7 @@ template <bool WHOLE_PENCILS>
 __global__ void __launch_bounds__(PC_G_WAVES * 64, 4)   // registers and LDS admit 5 waves per SIMD
 pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T, int x_lo, int x_hi,
                    unsigned int *__restrict__ queue, uint32_t seg_cap, uint32_t heavy_cap,
-                   int gate, uint32_t gate_limit, unsigned long long *__restrict__ out)
+                   int gate, uint32_t gate_limit, unsigned long long *__restrict__ out, const float d2max)
 {
     if (!pc_gate_open(queue, gate, gate_limit)) return;
     __shared__ pc_group_lds lds_all[PC_G_WAVES];
@@ -586,11 +586,11 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                     // (mean = 3 * tot_m / cells, compared without dividing)
                     const uint32_t m3 = 3u * tot_m, cells = (uint32_t)(t_last + 1);
                     uint32_t hits;
-                    if (m3 < 4 * cells) hits = pc_g_window<2, 2>(L, nh, lane);
-                    else if (m3 < 10 * cells) hits = pc_g_window<2, 4>(L, nh, lane);
-                    else if (m3 < 23 * cells) hits = pc_g_window<2, 8>(L, nh, lane);
-                    else if (m3 < 50 * cells) hits = pc_g_window<4, 8>(L, nh, lane);
-                    else if (m3 < 107 * cells) hits = pc_g_window<8, 8>(L, nh, lane);
+                    if (m3 < 4 * cells) hits = pc_g_window<2, 2>(L, nh, lane, d2max);
+                    else if (m3 < 10 * cells) hits = pc_g_window<2, 4>(L, nh, lane, d2max);
+                    else if (m3 < 23 * cells) hits = pc_g_window<2, 8>(L, nh, lane, d2max);
+                    else if (m3 < 50 * cells) hits = pc_g_window<4, 8>(L, nh, lane, d2max);
+                    else if (m3 < 107 * cells) hits = pc_g_window<8, 8>(L, nh, lane, d2max);
                     else {
                         // dense window: per home cell, candidates stay in registers while the
                         // cell's home particles stream by
@@ -598,7 +598,7 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                         for (int t = th0; t < t_last; t++) {
                             const uint32_t c_lo = pc_lane_value(lo_m, t), c_hi = pc_lane_value(hi_m, t);
                             const uint32_t hb = pc_lane_value(ex_h, t), he = hb + pc_lane_value(n[0], t);
-                            hits += pc_g_block<false>(L, c_lo, c_hi, hb, he, lane);
+                            hits += pc_g_block<false>(L, c_lo, c_hi, hb, he, lane, d2max);
                         }
                         // same pencil (the steps above count these themselves): lane per home particle
                         for (uint32_t hp = lane; hp < nh; hp += 64) {
@@ -610,7 +610,7 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                                 const pc_v2f x = {L.hx[k2], L.hx[k2 + 1]}, y = {L.hy[k2], L.hy[k2 + 1]}, z = {L.hz[k2], L.hz[k2 + 1]};
                                 const pc_v2f dx = ax - x, dy = ay - y, dz = az - z;
                                 const pc_v2f sq = (dx * dx + dy * dy) + dz * dz;
-                                cnt += (sq.x <= 0.0025f) + ((sq.y <= 0.0025f) & (k2 + 1 < end));
+                                cnt += (sq.x <= d2max) + ((sq.y <= d2max) & (k2 + 1 < end));
                             }
                             acc += cnt;
                         }
@@ -680,8 +680,8 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                             }
                             pc_dma_wait();
                             pc_wave_lds_sync();
-                            const uint32_t hits = r == 0 ? pc_g_block<true>(L, 0, cnt, 0, nhb, lane)
-                                                         : pc_g_block<false>(L, 0, cnt, 0, nhb, lane);
+                            const uint32_t hits = r == 0 ? pc_g_block<true>(L, 0, cnt, 0, nhb, lane, d2max)
+                                                         : pc_g_block<false>(L, 0, cnt, 0, nhb, lane, d2max);
                             if (lane == 0) acc += hits;
                             pc_wave_lds_sync();
                         }
@@ -712,7 +712,7 @@ typedef float pc_hv4 __attribute__((ext_vector_type(4)));
 // MASKED: candidate slot q pairs with a home particle in slot p only if q > p (i0, i1 = p - t0)
 template <bool MASKED>
 __device__ __forceinline__ uint32_t pc_hv_tile(const float *__restrict__ pts, pc_hv4 *tile, uint32_t t0, uint32_t cnt,
-                                               pc_v2f h0xy, float h0z, pc_v2f h1xy, float h1z, int i0, int i1)
+                                               pc_v2f h0xy, float h0z, pc_v2f h1xy, float h1z, int i0, int i1, float d2max)
 {
     struct pt3 { float x, y, z; };
     const pt3 *P = reinterpret_cast<const pt3 *>(pts);
@@ -738,7 +738,7 @@ __device__ __forceinline__ uint32_t pc_hv_tile(const float *__restrict__ pts, pc
             const float e0 = h0z - c.z, e1 = h1z - c.z;
             const pc_v2f q0 = d0 * d0, q1 = d1 * d1;
             const float s0 = (q0.x + q0.y) + e0 * e0, s1 = (q1.x + q1.y) + e1 * e1;
-            unsigned long long b0 = __builtin_amdgcn_ballot_w64(s0 <= 0.0025f), b1 = __builtin_amdgcn_ballot_w64(s1 <= 0.0025f);
+            unsigned long long b0 = __builtin_amdgcn_ballot_w64(s0 <= d2max), b1 = __builtin_amdgcn_ballot_w64(s1 <= d2max);
             if (MASKED) {
                 b0 &= __builtin_amdgcn_ballot_w64(i + u > i0);
                 b1 &= __builtin_amdgcn_ballot_w64(i + u > i1);
@@ -751,7 +751,7 @@ __device__ __forceinline__ uint32_t pc_hv_tile(const float *__restrict__ pts, pc
 
 __global__ void __launch_bounds__(PC_HV_TPB)
 pc_c3_heavy(const float *__restrict__ pts, const uint32_t *__restrict__ T, const unsigned int *__restrict__ work,
-            uint32_t heavy_cap, unsigned long long *__restrict__ out)
+            uint32_t heavy_cap, unsigned long long *__restrict__ out, const float d2max)
 {
     static_assert(PC_G_HEAVY_CHUNK == 2 * PC_HV_TPB && PC_HV_TILE == PC_G_HEAVY_CHUNK, "two home particles per thread, home chunk = one tile");
     const uint32_t items = min(work[PC_G_HEAVY_COUNT], heavy_cap);
@@ -798,9 +798,9 @@ pc_c3_heavy(const float *__restrict__ pts, const uint32_t *__restrict__ T, const
                 if (r == q) { lo_r = lo[q]; hi_r = T[key + base[q] + 3]; ft = first_tile[q]; }
             const uint32_t t0 = lo_r + (t - ft) * PC_HV_TILE, cnt = min((uint32_t)PC_HV_TILE, hi_r - t0);
             if (t == 0)
-                hits += pc_hv_tile<true>(pts, tile, t0, cnt, h0xy, m0.z, h1xy, m1.z, (int)threadIdx.x, (int)threadIdx.x + PC_HV_TPB);
+                hits += pc_hv_tile<true>(pts, tile, t0, cnt, h0xy, m0.z, h1xy, m1.z, (int)threadIdx.x, (int)threadIdx.x + PC_HV_TPB, d2max);
             else
-                hits += pc_hv_tile<false>(pts, tile, t0, cnt, h0xy, m0.z, h1xy, m1.z, 0, 0);
+                hits += pc_hv_tile<false>(pts, tile, t0, cnt, h0xy, m0.z, h1xy, m1.z, 0, 0, d2max);
         }
         if ((threadIdx.x & 63) == 0) acc += hits;
     }

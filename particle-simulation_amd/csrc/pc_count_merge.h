@@ -104,7 +104,7 @@ __device__ __forceinline__ void pc_m_request(uint32_t ap, pc_v4f *a, std::intege
 
 // NS slots of every lane against its group's home particle: hits of the whole wave
 template <int G, int NS>
-__device__ __forceinline__ uint32_t pc_m_test(uint32_t ap, pc_v2f hxy, float hz)
+__device__ __forceinline__ uint32_t pc_m_test(uint32_t ap, pc_v2f hxy, float hz, float d2max)
 {
     pc_v4f a[NS];
     float sq[NS];
@@ -120,13 +120,13 @@ __device__ __forceinline__ uint32_t pc_m_test(uint32_t ap, pc_v2f hxy, float hz)
     }
     uint32_t hits = 0;
 #pragma unroll
-    for (int k = 0; k < NS; k++) hits += __popcll(__builtin_amdgcn_ballot_w64(sq[k] <= 0.0025f));
+    for (int k = 0; k < NS; k++) hits += __popcll(__builtin_amdgcn_ballot_w64(sq[k] <= d2max));
     return hits;
 }
 
 // All nh home particles of the staged window, 64/G per step.
 template <int G>
-__device__ __forceinline__ uint32_t pc_m_steps(const pc_merge_lds &L, uint32_t nh, uint32_t tot, int lane)
+__device__ __forceinline__ uint32_t pc_m_steps(const pc_merge_lds &L, uint32_t nh, uint32_t tot, int lane, float d2max)
 {
     constexpr int H = 64 / G;
     constexpr int NS0 = G <= 4 ? 8 : G == 8 ? PC_M_NS8 : 4;   // slots per lane before the run's end is looked at (G * NS0 <= 64)
@@ -144,12 +144,12 @@ __device__ __forceinline__ uint32_t pc_m_steps(const pc_merge_lds &L, uint32_t n
         const float hz = h.z;
         uint32_t p = q + 1 + j;                          // the lane's first slot
         int rem = (int)(e >> 16) - (int)p;                // slots from there to the end of the run
-        hits += pc_m_test<G, NS0>(pt_lds + 16 * p, hxy, hz);
+        hits += pc_m_test<G, NS0>(pt_lds + 16 * p, hxy, hz, d2max);
         rem -= G * NS0;
         p += G * NS0;
         while (__builtin_amdgcn_ballot_w64(rem > 0) != 0) {
             p = min(p, tot);                              // finished lanes wait on the never-matching slots
-            hits += pc_m_test<G, 2>(pt_lds + 16 * p, hxy, hz);
+            hits += pc_m_test<G, 2>(pt_lds + 16 * p, hxy, hz, d2max);
             rem -= 2 * G;
             p += 2 * G;
         }
@@ -161,7 +161,7 @@ __device__ __forceinline__ uint32_t pc_m_steps(const pc_merge_lds &L, uint32_t n
 // list of pc_c3_count_groups if there is room, else counted here and now.
 __device__ __forceinline__ unsigned long long pc_m_defer(const float *__restrict__ pts, const uint32_t *__restrict__ T,
                                                          unsigned int *__restrict__ queue, uint32_t seg_cap,
-                                                         uint32_t pencil, int z0, uint32_t home_hi, int lane)
+                                                         uint32_t pencil, int z0, uint32_t home_hi, int lane, const pc_geom &geo)
 {
     uint32_t at = 0xFFFFFFFFu;
     if (lane == 0 && seg_cap != 0) {
@@ -175,14 +175,14 @@ __device__ __forceinline__ unsigned long long pc_m_defer(const float *__restrict
     if (at < seg_cap) return 0;
     unsigned long long acc = 0;
     for (uint64_t p = (uint64_t)T[(uint64_t)pencil * PC_NBB + z0] + lane; p < home_hi; p += 64)
-        acc += pc_count_one_home(pts, T, (uint32_t)p);
+        acc += pc_count_one_home(pts, T, (uint32_t)p, geo);
     return acc;
 }
 
 __global__ void __launch_bounds__(64, 6)
 pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T, int x_lo, int x_hi,
                    unsigned int *__restrict__ queue, uint32_t seg_cap, int gate, uint32_t gate_limit,
-                   unsigned long long *__restrict__ out)
+                   unsigned long long *__restrict__ out, const pc_geom geo)
 {
     if (!pc_gate_open(queue, gate, gate_limit)) return;
     __shared__ pc_merge_lds L;
@@ -268,7 +268,7 @@ pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T
             // run lengths: three blocks on average; beyond about 130 slots variant 3's kernel does better
             const bool suited = fits && 3u * tot <= 130u * (uint32_t)nblk;
             if (!suited) {
-                const unsigned long long slow = pc_m_defer(pts, T, queue, seg_cap, pencil, z0, home_hi, lane);
+                const unsigned long long slow = pc_m_defer(pts, T, queue, seg_cap, pencil, z0, home_hi, lane, geo);
                 acc += slow;
                 break;
             }
@@ -331,10 +331,10 @@ pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T
                 hits = 0;
                 if (m3 == 0xFFFFFFFFu)
 #endif
-                if (m3 <= 12u * blocks) hits = pc_m_steps<2>(L, nh, tot, lane);
-                else if (m3 <= PC_M_G4_MAX * blocks) hits = pc_m_steps<4>(L, nh, tot, lane);
-                else if (m3 <= 60u * blocks) hits = pc_m_steps<8>(L, nh, tot, lane);
-                else hits = pc_m_steps<16>(L, nh, tot, lane);
+                if (m3 <= 12u * blocks) hits = pc_m_steps<2>(L, nh, tot, lane, geo.d2max);
+                else if (m3 <= PC_M_G4_MAX * blocks) hits = pc_m_steps<4>(L, nh, tot, lane, geo.d2max);
+                else if (m3 <= 60u * blocks) hits = pc_m_steps<8>(L, nh, tot, lane, geo.d2max);
+                else hits = pc_m_steps<16>(L, nh, tot, lane, geo.d2max);
                 if (lane == 0) acc += hits;
                 pc_wave_lds_sync();
             }

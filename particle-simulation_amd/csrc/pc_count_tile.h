@@ -48,25 +48,25 @@ struct pc_tile_lds {
 
 // count hits of (x,y,z) against LDS candidates [lo,hi)
 __device__ __forceinline__ uint32_t pc_tile_scan(const pc_tile_lds &L, float x, float y, float z,
-                                                 uint32_t lo, uint32_t hi)
+                                                 uint32_t lo, uint32_t hi, float d2max)
 {
     uint32_t c = 0;
-    for (uint32_t q = lo; q < hi; q++) c += pc_hit(x, y, z, L.x[q], L.y[q], L.z[q]);
+    for (uint32_t q = lo; q < hi; q++) c += pc_hit(x, y, z, L.x[q], L.y[q], L.z[q], d2max);
     return c;
 }
 
 __device__ __forceinline__ uint32_t pc_global_scan(const float *__restrict__ pts, float x, float y, float z,
-                                                   uint32_t lo, uint32_t hi)
+                                                   uint32_t lo, uint32_t hi, float d2max)
 {
     uint32_t c = 0;
     for (uint32_t q = lo; q < hi; q++)
-        c += pc_hit(x, y, z, pts[3 * (uint64_t)q], pts[3 * (uint64_t)q + 1], pts[3 * (uint64_t)q + 2]);
+        c += pc_hit(x, y, z, pts[3 * (uint64_t)q], pts[3 * (uint64_t)q + 1], pts[3 * (uint64_t)q + 2], d2max);
     return c;
 }
 
 __global__ void __launch_bounds__(PC_T_TPB)
 pc_c1_count_tiles(const float *__restrict__ pts, const uint32_t *__restrict__ T, int x_lo, int x_hi,
-                  unsigned long long *__restrict__ out)
+                  unsigned long long *__restrict__ out, const pc_geom geo)
 {
     __shared__ pc_tile_lds L;
     const int tid = threadIdx.x;
@@ -122,11 +122,11 @@ pc_c1_count_tiles(const float *__restrict__ pts, const uint32_t *__restrict__ T,
                         for (int t = 1; t < PC_T_S; t++) h += gidx >= hb[t];
                         uint32_t i = L.slice[h][z0] + (gidx - hb[h]);
                         float x = pts[3 * (uint64_t)i], y = pts[3 * (uint64_t)i + 1], z = pts[3 * (uint64_t)i + 2];
-                        uint32_t c = pc_global_scan(pts, x, y, z, i + 1, L.slice[h][z0 + 2]);
+                        uint32_t c = pc_global_scan(pts, x, y, z, i + 1, L.slice[h][z0 + 2], geo.d2max);
                         const int rows[4] = {h + 1, PC_T_S + 1 + h, PC_T_S + 2 + h, PC_T_S + 3 + h};
 #pragma unroll
                         for (int t = 0; t < 4; t++)
-                            c += pc_global_scan(pts, x, y, z, L.slice[rows[t]][zl], L.slice[rows[t]][z0 + 2]);
+                            c += pc_global_scan(pts, x, y, z, L.slice[rows[t]][zl], L.slice[rows[t]][z0 + 2], geo.d2max);
                         acc += c;
                     }
                     z0 += 1;
@@ -175,17 +175,17 @@ pc_c1_count_tiles(const float *__restrict__ pts, const uint32_t *__restrict__ T,
                         const uint32_t i = L.slice[h][z0] + (gidx - L.home_base[h]);     // global slot
                         const uint32_t li = L.row_base[h] + (i - L.row_lo[h]);           // LDS index
                         const float x = L.x[li], y = L.y[li], z = L.z[li];
-                        const int k = pc_cell_index(z);
+                        const int k = pc_cell_index(z, geo);
                         const int kl = k > 0 ? k - 1 : 0;
                         // same cell, later slots + cell k+1 of the home pencil (main.c:215-221, (0,0,1))
                         uint32_t c = pc_tile_scan(L, x, y, z, li + 1,
-                                                  L.row_base[h] + (L.slice[h][k + 2] - L.row_lo[h]));
+                                                  L.row_base[h] + (L.slice[h][k + 2] - L.row_lo[h]), geo.d2max);
                         const int rows[4] = {h + 1, PC_T_S + 1 + h, PC_T_S + 2 + h, PC_T_S + 3 + h};
 #pragma unroll
                         for (int t = 0; t < 4; t++) {
                             const int r = rows[t];
                             const uint32_t off = L.row_base[r] - L.row_lo[r];
-                            c += pc_tile_scan(L, x, y, z, off + L.slice[r][kl], off + L.slice[r][k + 2]);
+                            c += pc_tile_scan(L, x, y, z, off + L.slice[r][kl], off + L.slice[r][k + 2], geo.d2max);
                         }
                         acc += c;
                     }

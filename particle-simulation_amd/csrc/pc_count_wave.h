@@ -37,7 +37,7 @@ struct pc_wave_lds {
 
 // hits of (x,y,z) against LDS records [lo,hi)
 __device__ __forceinline__ uint32_t pc_w_scan(const float4 *__restrict__ cand, float x, float y, float z,
-                                              uint32_t lo, uint32_t hi)
+                                              uint32_t lo, uint32_t hi, float d2max)
 {
     // four candidates per trip so that four LDS reads are in flight; slots past
     // hi are read (clamped into the buffer) and masked out
@@ -47,10 +47,10 @@ __device__ __forceinline__ uint32_t pc_w_scan(const float4 *__restrict__ cand, f
         const float4 v1 = cand[min(q + 1, (uint32_t)PC_W_CAP - 1)];
         const float4 v2 = cand[min(q + 2, (uint32_t)PC_W_CAP - 1)];
         const float4 v3 = cand[min(q + 3, (uint32_t)PC_W_CAP - 1)];
-        c += pc_hit(x, y, z, v0.x, v0.y, v0.z);
-        c += (q + 1 < hi) & pc_hit(x, y, z, v1.x, v1.y, v1.z);
-        c += (q + 2 < hi) & pc_hit(x, y, z, v2.x, v2.y, v2.z);
-        c += (q + 3 < hi) & pc_hit(x, y, z, v3.x, v3.y, v3.z);
+        c += pc_hit(x, y, z, v0.x, v0.y, v0.z, d2max);
+        c += (q + 1 < hi) & pc_hit(x, y, z, v1.x, v1.y, v1.z, d2max);
+        c += (q + 2 < hi) & pc_hit(x, y, z, v2.x, v2.y, v2.z, d2max);
+        c += (q + 3 < hi) & pc_hit(x, y, z, v3.x, v3.y, v3.z, d2max);
     }
     return c;
 }
@@ -67,7 +67,7 @@ __device__ __forceinline__ void pc_w_fill(float4 *__restrict__ cand, uint32_t ds
 
 __global__ void __launch_bounds__(PC_W_WAVES * 64)
 pc_c2_count_waves(const float *__restrict__ pts, const uint32_t *__restrict__ T, int x_lo, int x_hi,
-                  unsigned long long *__restrict__ out)
+                  unsigned long long *__restrict__ out, const pc_geom geo)
 {
     __shared__ pc_wave_lds lds_all[PC_W_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -138,13 +138,13 @@ pc_c2_count_waves(const float *__restrict__ pts, const uint32_t *__restrict__ T,
                     for (uint32_t i = h0 + lane; i < h1; i += 64) {
                         const uint32_t li = i - lo_r[0];
                         const float4 me = L.cand[li];
-                        const int k = pc_cell_index(me.z);
+                        const int k = pc_cell_index(me.z, geo);
                         const int kl = k > 0 ? k - 1 : 0;
-                        uint32_t c = pc_w_scan(L.cand, me.x, me.y, me.z, li + 1, L.slice[0][k + 2] - lo_r[0]);
+                        uint32_t c = pc_w_scan(L.cand, me.x, me.y, me.z, li + 1, L.slice[0][k + 2] - lo_r[0], geo.d2max);
 #pragma unroll
                         for (int r = 1; r < 5; r++) {
                             const uint32_t off = base_r[r] - lo_r[r];
-                            c += pc_w_scan(L.cand, me.x, me.y, me.z, off + L.slice[r][kl], off + L.slice[r][k + 2]);
+                            c += pc_w_scan(L.cand, me.x, me.y, me.z, off + L.slice[r][kl], off + L.slice[r][k + 2], geo.d2max);
                         }
                         acc += c;
                     }
@@ -168,7 +168,7 @@ pc_c2_count_waves(const float *__restrict__ pts, const uint32_t *__restrict__ T,
                                 const float x = p[0], y = p[1], z = p[2];
                                 uint32_t s = 0;
                                 if (r == 0 && i + 1 > p0) s = min(i + 1 - p0, cnt);   // only slots after i
-                                acc += pc_w_scan(L.cand, x, y, z, s, cnt);
+                                acc += pc_w_scan(L.cand, x, y, z, s, cnt, geo.d2max);
                             }
                             pc_wave_lds_sync();
                         }

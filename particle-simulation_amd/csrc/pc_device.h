@@ -8,15 +8,29 @@
 #define PC_NBB2 (PC_NBB * PC_NBB)
 #define PC_WAVE 64
 
+// Geometry of a run, passed to every kernel by value.  The reference hard-codes it
+// (main.c:30-31,134-136,165: domain from -10, cell edge BBSIZE 0.05, threshold 0.0025);
+// pc_geom_default() is exactly that, and other values go through the same arithmetic.
+// The table keeps its 403 cells per axis whatever ncell is: cells from ncell on are
+// simply never occupied (a point that maps there is outside the domain).
+struct pc_geom {
+    double add;        // minus the lower domain bound: cell = (int)(((double)f + add) / cell)
+    double cell;       // cell edge
+    float addf, invf;  // binary32 shortcut: floor((f + addf) * invf) away from cell boundaries
+    float hi;          // the shortcut is used for quotients in [0, hi)
+    int ncell;         // occupied cells per axis, at most PC_NLAYERS
+    float d2max;       // squared cutoff: a pair counts if (dx*dx + dy*dy) + dz*dz <= d2max
+};
+
 // Cell index along one axis: reference main.c:134-136,
 //   (int)((f - (-10.)) / 0.05)   with f promoted to double.
 // f - (-10.0) and f + 10.0 are the same IEEE operation; the divide must stay a
 // correctly rounded binary64 division (no reciprocal multiply).
 // A NaN or a quotient beyond int converts to INT_MIN, as cvttsd2si does in the
 // reference's build (the GPU conversion would give 0 for NaN: a valid cell).
-__device__ __forceinline__ int pc_cell_index_exact(float f)
+__device__ __forceinline__ int pc_cell_index_exact(float f, const pc_geom &g)
 {
-    const double q = ((double)f + 10.0) / 0.05;
+    const double q = ((double)f + g.add) / g.cell;
     if (!(q > -2147483649.0 && q < 2147483648.0)) return (int)0x80000000;
     return (int)q;
 }
@@ -29,14 +43,16 @@ __device__ __forceinline__ int pc_cell_index_exact(float f)
 // 1e-3 away from an integer, floor(u) == floor(q) == the reference's index.
 // Points closer to a cell boundary, negative u and everything outside the grid
 // take the reference's formula itself.  pc_selfcheck_cell_index_device compares
-// the two functions over all 2^32 bit patterns.
-__device__ __forceinline__ int pc_cell_index(float f)
+// the two functions over all 2^32 bit patterns.  (For another geometry the host
+// checks that the same error budget holds -- the rounding of addf and invf enter it --
+// and otherwise sets hi = 0, which sends every point through the exact formula.)
+__device__ __forceinline__ int pc_cell_index(float f, const pc_geom &g)
 {
-    const float u = __fmul_rn(__fadd_rn(f, 10.0f), 20.0f);
+    const float u = __fmul_rn(__fadd_rn(f, g.addf), g.invf);
     const float fl = floorf(u);
     const float fr = __fsub_rn(u, fl);
     int c = (int)fl;
-    if (!(fr >= 1.0e-3f && fr <= 0.999f && u >= 0.0f && u < 400.5f)) c = pc_cell_index_exact(f);
+    if (!(fr >= 1.0e-3f && fr <= 0.999f && u >= 0.0f && u < g.hi)) c = pc_cell_index_exact(f, g);
     return c;
 }
 
@@ -46,9 +62,10 @@ __device__ __forceinline__ uint32_t pc_key(int i, int j, int k)
     return (uint32_t)(i * PC_NBB2 + j * PC_NBB + k);
 }
 
-__device__ __forceinline__ bool pc_in_grid(int i, int j, int k)
+__device__ __forceinline__ bool pc_in_grid(int i, int j, int k, const pc_geom &g)
 {
-    return ((unsigned)i < 400u) & ((unsigned)j < 400u) & ((unsigned)k < 400u);
+    const unsigned nc = (unsigned)g.ncell;
+    return ((unsigned)i < nc) & ((unsigned)j < nc) & ((unsigned)k < nc);
 }
 
 // Distance predicate: reference main.c:85-91 (dpps imm 0x71) and main.c:165.
@@ -56,11 +73,11 @@ __device__ __forceinline__ bool pc_in_grid(int i, int j, int k)
 // rounded binary32 operation -- __fmul_rn/__fadd_rn are never contracted into
 // an FMA.  (double)d2 <= 0.0025 is equivalent to d2 <= 0.0025f because
 // 0.0025f < 0.0025 < nextafterf(0.0025f, 1).
-__device__ __forceinline__ bool pc_hit(float xi, float yi, float zi, float xj, float yj, float zj)
+__device__ __forceinline__ bool pc_hit(float xi, float yi, float zi, float xj, float yj, float zj, float d2max)
 {
     float dx = __fsub_rn(xi, xj), dy = __fsub_rn(yi, yj), dz = __fsub_rn(zi, zj);
     float s = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-    return s <= 0.0025f;
+    return s <= d2max;
 }
 
 // Orders one wave's LDS traffic: LDS operations of a wave complete in issue

@@ -39,6 +39,10 @@ class Oracle:
                                       c.POINTER(c.c_int64), c.c_void_p, c.c_void_p]
         L.orc_count_pairs_bruteforce.restype = c.c_int64
         L.orc_count_pairs_bruteforce.argtypes = [c.c_void_p, c.c_uint64]
+        L.orc_count_pairs_anycell.restype = c.c_int64
+        L.orc_count_pairs_anycell.argtypes = [c.c_void_p, c.c_uint64]
+        L.orc_set_geometry.restype = None
+        L.orc_set_geometry.argtypes = [c.c_double, c.c_double, c.c_int, c.c_float]
         self.L = L
 
     def parse_token(self, tok):
@@ -87,6 +91,15 @@ class Oracle:
         if want_sorted:
             return int(r), int(tests.value), srt[:n], start
         return int(r), int(tests.value)
+
+    def set_geometry(self, origin=-10.0, cell=0.05, ncell=400, d2max=0.0025):
+        """Other constants for the same expressions (process-wide; call with no arguments to restore the reference's)."""
+        self.L.orc_set_geometry(origin, cell, ncell, d2max)
+
+    def brute_anycell(self, xyz):
+        """All pairs within the cutoff, no grid involved (O(n^2))."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        return int(self.L.orc_count_pairs_anycell(xyz.ctypes.data, xyz.shape[0]))
 
     def brute(self, xyz):
         xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)

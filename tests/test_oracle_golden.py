@@ -117,3 +117,22 @@ def test_slab_decomposition_sums_to_whole(oracle):
 def test_out_of_domain_rejected(oracle):
     with pytest.raises(ValueError):
         oracle.count_pairs(np.array([[10.5, 0, 0]], dtype=np.float32))
+
+
+def test_other_geometry_stencil_count_equals_all_pairs_brute_force(oracle):
+    """With another geometry (nothing of the reference pins it) the binned stencil count of the checker must
+    equal the count over ALL pairs, as long as the cutoff does not exceed the cell edge."""
+    rng = np.random.default_rng(11)
+    try:
+        for origin, cell, ncell, cutoff, n in ((-10.0, 0.05, 400, 0.03, 3000), (0.0, 0.25, 37, 0.2, 2500),
+                                               (-3.0, 0.015, 400, 0.0149, 4000)):
+            d2max = float(np.float32(cutoff) * np.float32(cutoff))
+            oracle.set_geometry(origin, cell, ncell, d2max)
+            lo, hi = origin + 1e-6, origin + ncell * cell * 0.2
+            xyz = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+            got, tests = oracle.count_pairs(xyz)
+            assert got == oracle.brute_anycell(xyz) == oracle.brute(xyz) and got > 0
+    finally:
+        oracle.set_geometry()
+    xyz = rng.uniform(-1, 1, (2000, 3)).astype(np.float32)
+    assert oracle.count_pairs(xyz)[0] == oracle.brute(xyz)
