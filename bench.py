@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--as-rank", type=int, nargs=2, metavar=("R", "W"), default=None,
                     help="single process, no collective: time the slab that rank R of a W-rank run would hold "
                          "(a per-rank preview of the N-GPU line on a one-GPU box; not a bench result)")
+    ap.add_argument("--event-period", type=int, default=4,
+                    help="per-kernel HIP events around every k-th launch of each kernel inside the timed region (1: all)")
     ap.add_argument("--no-e2e-full", action="store_true",
                     help="skip the full-size end-to-end leg of cpu_baseline (reference program and the product's host "
                          "program on the whole workload written as a text file)")
@@ -198,7 +200,9 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    psa.profile_enable(True)
+    # per-kernel HIP events on every 4th step of the timed region (on every step they cost 0.15 ms of a 3.7 ms
+    # step: 34 event records); PAIRCOUNT_BENCH_NO_EVENTS=1 switches them off to measure just that
+    psa.profile_enable(0 if os.environ.get("PAIRCOUNT_BENCH_NO_EVENTS") else args.event_period)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -244,7 +248,12 @@ def main():
         kernels = {}
         for name, (timed, launches, ms) in prof.items():
             if timed:
-                kernels[name] = {"avg_ms": ms / timed, "launches_per_step": launches / args.steps}
+                kernels[name] = {"avg_ms": ms / timed, "launches_per_step": launches / args.steps, "timed_launches": timed}
+        if not kernels:            # events switched off (PAIRCOUNT_BENCH_NO_EVENTS: what the events themselves cost)
+            print(json.dumps({"ms_per_step": ms_per_step, "events": False, "pairs": pairs, "tests": tests}))
+            if world > 1:
+                dist.destroy_process_group()
+            return
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches_per_step"])
         layers = x_hi - x_lo
         for name, k in kernels.items():

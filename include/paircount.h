@@ -211,7 +211,9 @@ int pc_set_variant(const char *name, int value);
 
 /* Per-kernel device timing for the stage functions above: while enabled, a
    pair of HIP events is recorded on the launch stream around each kernel.
-   pc_profile_enable(1) also clears earlier samples.  pc_profile_read waits for
+   pc_profile_enable(k), k > 1, times only launches 1, k+1, 2k+1, ... of each
+   kernel (a pair of events costs a few microseconds of stream time per
+   kernel).  Enabling also clears earlier samples.  pc_profile_read waits for
    the recorded events and writes one text line per kernel:
    "<kernel> <timed launches> <launches> <total ms of the timed launches>".
    A measurement aid, not thread-safe: enable it only while a single host

@@ -111,7 +111,8 @@ def set_variant(name, value):
 
 
 def profile_enable(on=True):
-    _check(lib().pc_profile_enable(1 if on else 0))
+    """on: False/0 off, True/1 every launch, k > 1 every k-th launch of each kernel."""
+    _check(lib().pc_profile_enable(int(on)))
 
 
 def profile_read():

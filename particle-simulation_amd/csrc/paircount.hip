@@ -182,12 +182,15 @@ struct pc_prof_scope {
     int idx = -1;
     pc_prof_scope(const char *name, hipStream_t stream) : st(stream)
     {
-        if (!g_prof_on.load(std::memory_order_relaxed)) return;
+        const int period = g_prof_on.load(std::memory_order_relaxed);
+        if (!period) return;
         pthread_mutex_lock(&g_prof_lock);
         s = prof_slot(name);
         if (s) {
             s->launches++;
-            if (s->used < PC_PROF_RING) {
+            // (period k: launches 1, k+1, 2k+1, ... of each kernel are timed -- the events themselves cost a few
+            // microseconds per kernel, which a caller timing whole steps may not want on every launch)
+            if (s->used < PC_PROF_RING && (period == 1 || s->launches % (unsigned)period == 1)) {
                 if (s->used == s->created && hipEventCreate(&s->ev[s->created][0]) == hipSuccess) {
                     if (hipEventCreate(&s->ev[s->created][1]) == hipSuccess) s->created++;
                     else (void)hipEventDestroy(s->ev[s->created][0]);
@@ -215,7 +218,7 @@ extern "C" int pc_profile_enable(int on)
     pthread_mutex_lock(&g_prof_lock);
     if (on)
         for (int i = 0; i < g_prof_n; i++) { g_prof[i].used = 0; g_prof[i].launches = 0; }
-    g_prof_on.store(on != 0, std::memory_order_relaxed);
+    g_prof_on.store(on > 0 ? on : 0, std::memory_order_relaxed);
     pthread_mutex_unlock(&g_prof_lock);
     return PC_OK;
 }
@@ -350,7 +353,7 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
     PC_LAUNCH("pc_l7b_sort_big_pencils", small, dim3(resident_blocks(small, PC_L7B_TPB_SMALL, &small_grid)), dim3(PC_L7B_TPB_SMALL), s, w.tmp, d_sorted, w.pencil_start, table,
               w.big_count, w.big_list, first_pencil, end_pencil, 0u, (uint32_t)PC_L7B_CAP_SMALL,
               (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, d_status, t_geo);
-    PC_LAUNCH("pc_l7b_sort_big_pencils", large, dim3(resident_blocks(large, PC_L7B_TPB_LARGE, &large_grid)), dim3(PC_L7B_TPB_LARGE), s, w.tmp, d_sorted, w.pencil_start, table,
+    PC_LAUNCH("pc_l7b_sort_bigger_pencils", large, dim3(resident_blocks(large, PC_L7B_TPB_LARGE, &large_grid)), dim3(PC_L7B_TPB_LARGE), s, w.tmp, d_sorted, w.pencil_start, table,
               w.big_count, w.big_list, first_pencil, end_pencil, (uint32_t)PC_L7B_CAP_SMALL, (uint32_t)PC_L7B_CAP_LARGE,
               w.big_count + 1, w.huge_list, w.huge_count, d_status, t_geo);
     // pencils beyond a workgroup's capacity (listed just now): tile-parallel histogram, scan, partition
@@ -583,7 +586,7 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
         }
         const int grid = ((want < most ? want : most) + 7) / 8 * 8;
         if (variant == 5) {
-            PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups<false>, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
+            PC_LAUNCH("pc_c3_count_groups_segments", pc_c3_count_groups<false>, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
                       d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap, PC_GATE_IF_EVEN, gate_limit,
                       (unsigned long long *)d_npairs, t_geo.d2max);
             PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups<true>, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,

@@ -22,7 +22,9 @@
 #include "pc_device.h"
 
 #define PC_L_TPB 256
+#ifndef PC_L_PPT
 #define PC_L_PPT 16
+#endif
 #define PC_L_TILE (PC_L_TPB * PC_L_PPT)        // 4096 points = 48 KB of LDS
 #define PC_L_PTPB 512                          // partition kernels: threads per tile
 #define PC_L_PPPT (PC_L_TILE / PC_L_PTPB)      // and points per thread
