@@ -52,6 +52,9 @@
 #define PC_M_SLACK 80                   // never-matching slots behind the last block: a lane's first pass reads at most 65 past it
 #define PC_M_LEN (PC_M_CAP + PC_M_SLACK)
 #define PC_M_MAX_G 16
+#ifndef PC_M_MAX_RUN
+#define PC_M_MAX_RUN 130u                 // longest mean run (slots) this kernel takes
+#endif
 #ifndef PC_M_NS8
 #define PC_M_NS8 8
 #endif
@@ -266,7 +269,7 @@ pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T
                 nh = pc_lane_value(cumh, w - 1);
             }
             // run lengths: three blocks on average; beyond about 130 slots variant 3's kernel does better
-            const bool suited = fits && 3u * tot <= 130u * (uint32_t)nblk;
+            const bool suited = fits && 3u * tot <= PC_M_MAX_RUN * (uint32_t)nblk;
             if (!suited) {
                 const unsigned long long slow = pc_m_defer(pts, T, queue, seg_cap, pencil, z0, home_hi, lane, geo);
                 acc += slow;
