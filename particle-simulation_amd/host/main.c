@@ -23,6 +23,13 @@
  * (every neighbour offset of the reference has dx in {0,+1}, main.c:195-209) -- the
  * slabs are finished concurrently and their counts added: the fold of the
  * counter threads' totals at main.c:231.  Without -g nothing changes.
+ * PAIRCOUNT_QUEUE=K (K >= 2, with or without -g) cuts the x range into K slabs that
+ * are not tied to a GPU: the parser threads keep each slab's points in host memory,
+ * and afterwards one thread per GPU takes the next slab from a shared counter -- most
+ * points first -- uploads it, counts it and comes back for more, until none is left.
+ * That is the reference's hand-out of work to its counter threads (an atomic cursor,
+ * main.c:192) one level up: a GPU that got sparse slabs takes more of them, so a
+ * clustered input needs no cost model to stay balanced.
  * With PAIRCOUNT_TIMER=1 in the environment the four phase times the
  * reference's -DTIMER build prints are written to stderr.
  */
@@ -30,6 +37,7 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <pthread.h>
+#include <stdatomic.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -44,6 +52,33 @@
 #define BLOCK_POINTS 65536
 #define MAX_SLABS 64
 #define LAYERS PC_NLAYERS
+#define CHUNK_POINTS_MIN 4096         /* host-memory chunk of a queued slab: each is one upload, and an */
+#define CHUNK_POINTS_MAX 262144       /* upload costs ~30 us before its first byte moves */
+
+/* points of one (parser thread, slab) held in host memory until a GPU takes the slab */
+typedef struct chunk {
+    struct chunk *next;
+    uint32_t n;
+    float xyz[];                 /* 3 * g_chunk_points */
+} chunk;
+
+/* Queued runs take their chunks from one page-locked arena (uploads from it run at the link's rate, from
+   pageable memory at a fraction of it); the library maps it lazily, so the parser threads' first touches
+   populate it in parallel.  When it runs out -- lines much shorter than the size estimate assumes -- chunks
+   come from malloc. */
+static char *g_arena;
+static size_t g_arena_chunks, g_chunk_bytes;
+static uint32_t g_chunk_points;
+static atomic_size_t g_arena_next;
+
+static chunk *new_chunk(void)
+{
+    if (g_arena) {
+        const size_t i = atomic_fetch_add(&g_arena_next, 1);
+        if (i < g_arena_chunks) return (chunk *)(g_arena + i * g_chunk_bytes);
+    }
+    return (chunk *)malloc(g_chunk_bytes);
+}
 
 /* the x slabs of a run (one slab, the whole grid, unless -g asks for more) */
 typedef struct {
@@ -53,6 +88,8 @@ typedef struct {
     pc_context *ctx[MAX_SLABS];
     unsigned char owner[LAYERS];     /* layer -> slab */
     uint32_t block_points;           /* capacity of one (thread, slab) block */
+    int queued;                      /* slabs wait in host memory for the next free GPU */
+    int gpus;                        /* queued: GPUs (taker threads), device[g] of taker g */
 } slab_set;
 
 typedef struct {
@@ -64,6 +101,8 @@ typedef struct {
     double append_us;        /* time this thread spent inside pc_append */
     float *block;            /* this thread's page-locked blocks: one of block_points points per slab */
     uint32_t fill[MAX_SLABS];
+    chunk *held[MAX_SLABS];  /* queued slabs: this thread's chunks, newest first */
+    uint64_t held_points[MAX_SLABS];
     int binary;              /* the file holds float triples, not text */
     char msg[256];
 } worker;
@@ -87,6 +126,19 @@ static int append_block(worker *w, int slab, const float *block, uint64_t n)
 /* one point into this thread's block of slab s; a full block is appended */
 static inline int put_point(worker *w, int s, const float *pt)
 {
+    if (w->slabs->queued) {
+        chunk *c = w->held[s];
+        if (!c || c->n == g_chunk_points) {
+            c = new_chunk();
+            if (!c) { w->status = 2; snprintf(w->msg, sizeof w->msg, "out of host memory for slab %d", s); return -1; }
+            c->next = w->held[s];
+            c->n = 0;
+            w->held[s] = c;
+        }
+        memcpy(c->xyz + 3 * (size_t)c->n++, pt, 12);
+        w->held_points[s]++;
+        return PC_OK;
+    }
     float *blk = w->block + (size_t)s * w->slabs->block_points * 3;
     memcpy(blk + 3 * (size_t)w->fill[s], pt, 12);
     if (++w->fill[s] == w->slabs->block_points) {
@@ -114,6 +166,7 @@ static inline int route_point(worker *w, const float *pt)
 
 static void flush_blocks(worker *w)
 {
+    if (w->slabs->queued) return;
     for (int s = 0; s < w->slabs->n && !w->status; s++)
         if (w->fill[s]) {
             append_block(w, s, w->block + (size_t)s * w->slabs->block_points * 3, w->fill[s]);
@@ -127,7 +180,7 @@ static void append_binary_share(worker *w)
     const uint64_t total = w->size / 12;
     const uint64_t first = total * (uint64_t)w->t / (uint64_t)w->nt, last = total * (uint64_t)(w->t + 1) / (uint64_t)w->nt;
     const float *pts = (const float *)w->file;
-    if (w->slabs->n == 1) {
+    if (w->slabs->n == 1 && !w->slabs->queued) {
         for (uint64_t i = first; i < last; i += 16 * BLOCK_POINTS) {
             const uint64_t m = last - i < 16 * BLOCK_POINTS ? last - i : 16 * BLOCK_POINTS;
             if (append_block(w, 0, pts + 3 * i, m) != PC_OK) return;
@@ -211,6 +264,58 @@ static void *finish_thread(void *arg)
     return NULL;
 }
 
+/* one GPU of a queued run: takes slabs from the shared cursor until none is left */
+typedef struct {
+    const slab_set *slabs;
+    worker *w;
+    int nt;
+    const int *order;            /* slabs, most points first */
+    const uint64_t *points;      /* points held per slab */
+    atomic_int *next, *failed;
+    int g;                       /* taker g runs on slabs->device[g] */
+    finisher *fin;               /* results, per slab */
+    int *taken_by;               /* per slab: the taker that counted it */
+    double *busy_us;             /* per taker */
+    double part_us[4];           /* this taker's time in create, append, finish, destroy */
+} taker;
+
+static void *taker_thread(void *arg)
+{
+    taker *k = (taker *)arg;
+    const slab_set *S = k->slabs;
+    const double t0 = now_us();
+    for (;;) {
+        const int i = atomic_fetch_add(k->next, 1);
+        if (i >= S->n || atomic_load(k->failed)) break;
+        const int s = k->order[i];
+        finisher *f = &k->fin[s];
+        k->taken_by[s] = k->g;
+        if (k->points[s] == 0) continue;                 /* nothing in it: no pairs */
+        pc_context *ctx = NULL;
+        double t = now_us(), u;
+        f->rc = pc_create(&ctx, S->device[k->g], k->points[s]);
+        if (f->rc == PC_OK) f->rc = pc_set_slab(ctx, S->cut[s], S->cut[s + 1]);
+        k->part_us[0] += (u = now_us()) - t;
+        for (int t = 0; t < k->nt && f->rc == PC_OK; t++)
+            for (const chunk *c = k->w[t].held[s]; c && f->rc == PC_OK; c = c->next)
+                f->rc = pc_append(ctx, c->xyz, c->n);
+        k->part_us[1] += (t = now_us()) - u;
+        if (f->rc == PC_OK) {
+            f->ctx = ctx;
+            finish_thread(f);
+        } else {
+            snprintf(f->msg, sizeof f->msg, "%s", pc_last_error());
+        }
+        k->part_us[2] += (u = now_us()) - t;
+        if (ctx) pc_destroy(ctx);
+        k->part_us[3] += now_us() - u;
+        f->ctx = NULL;
+        if (f->rc != PC_OK) atomic_store(k->failed, 1);
+    }
+    k->busy_us[k->g] = now_us() - t0;
+    return NULL;
+}
+
 static void usage(char **argv)
 {
     printf("Usage: %s -f <data file> [-p NUM] [-c NUM] [-g NUM]\n", argv[0]);
@@ -256,6 +361,7 @@ int main(int argc, char **argv)
         }
     }
     (void)cthreads;
+    if (pthreads > 256) pthreads = 256;
     /* no -f: the reference passes its NULL file name to open(), which fails with EFAULT (main.c:297-300) */
     if (!file_name) errno = EFAULT;
     int fd = file_name ? open(file_name, O_RDONLY) : -1;
@@ -295,7 +401,16 @@ int main(int argc, char **argv)
     /* the slabs: equal widths unless PAIRCOUNT_CUTS names them; slab s on GPU s unless PAIRCOUNT_DEVICES does */
     static slab_set S;
     if (gpus > MAX_SLABS) gpus = MAX_SLABS;
-    S.n = gpus;
+    S.n = S.gpus = gpus;
+    if (getenv("PAIRCOUNT_QUEUE")) {
+        const int k = atoi(getenv("PAIRCOUNT_QUEUE"));
+        if (k < 2 || k > MAX_SLABS || k < gpus) {
+            fprintf(stderr, "PAIRCOUNT_QUEUE: need a slab count from %d to %d\n", gpus > 2 ? gpus : 2, MAX_SLABS);
+            return -1;
+        }
+        S.n = k;
+        S.queued = 1;
+    }
     for (int s = 0; s <= S.n; s++) S.cut[s] = LAYERS * s / S.n;
     if (getenv("PAIRCOUNT_CUTS")) {
         int c[MAX_SLABS + 1];
@@ -305,18 +420,20 @@ int main(int argc, char **argv)
         if (!ok) { fprintf(stderr, "PAIRCOUNT_CUTS: need %d increasing layers from 0 to %d\n", S.n + 1, LAYERS); return -1; }
         memcpy(S.cut, c, sizeof(int) * (size_t)(S.n + 1));
     }
+    /* device[] is per slab, or per GPU of a queued run */
+    const int ndev = S.queued ? S.gpus : S.n;
     for (int s = 0; s < S.n; s++) {
-        S.device[s] = S.n == 1 && getenv("PAIRCOUNT_DEVICE") ? atoi(getenv("PAIRCOUNT_DEVICE")) : s;
+        S.device[s] = ndev == 1 && getenv("PAIRCOUNT_DEVICE") ? atoi(getenv("PAIRCOUNT_DEVICE")) : s;
         for (int l = S.cut[s]; l < S.cut[s + 1]; l++) S.owner[l] = (unsigned char)s;
     }
     if (getenv("PAIRCOUNT_DEVICES") &&
-        parse_int_list(getenv("PAIRCOUNT_DEVICES"), S.device, S.n) != S.n) {
-        fprintf(stderr, "PAIRCOUNT_DEVICES: need %d device ordinals\n", S.n);
+        parse_int_list(getenv("PAIRCOUNT_DEVICES"), S.device, ndev) != ndev) {
+        fprintf(stderr, "PAIRCOUNT_DEVICES: need %d device ordinals\n", ndev);
         return -1;
     }
     S.block_points = S.n == 1 ? BLOCK_POINTS : (BLOCK_POINTS / (uint32_t)S.n < 4096 ? 4096 : BLOCK_POINTS / (uint32_t)S.n);
     const uint64_t expect = binary ? size / 12 + 1 : size / 24 + 1024;
-    for (int s = 0; s < S.n; s++) {
+    for (int s = 0; s < S.n && !S.queued; s++) {
         /* capacity hint: the slab's share of the points, with room for its halo layer and some imbalance */
         const uint64_t hint = S.n == 1 ? expect : expect * (uint64_t)(S.cut[s + 1] - S.cut[s] + 2) / LAYERS + 4096;
         if (pc_create(&S.ctx[s], S.device[s], hint) != PC_OK ||
@@ -325,16 +442,25 @@ int main(int argc, char **argv)
             return -1;
         }
     }
+    if (S.queued && size) {
+        /* every point once, a halo layer per slab, and a part-filled chunk per (thread, slab) */
+        /* chunk size: about two per (thread, slab) of evenly spread points, within the limits above */
+        const size_t lists = (size_t)pthreads * (size_t)S.n;
+        g_chunk_points = CHUNK_POINTS_MIN;
+        while (g_chunk_points < CHUNK_POINTS_MAX && (uint64_t)g_chunk_points * 2 * lists < expect) g_chunk_points *= 2;
+        g_chunk_bytes = (sizeof(chunk) + 12 * (size_t)g_chunk_points + 63) & ~(size_t)63;
+        g_arena_chunks = (size_t)(expect + expect * (uint64_t)S.n / LAYERS) / g_chunk_points + lists + 1;
+        if (pc_host_alloc((void **)&g_arena, (uint64_t)g_arena_chunks * g_chunk_bytes) != PC_OK) g_arena = NULL;
+    }
     if (timer) fprintf(stderr, "%16s:  %10.0f us\n", "init", now_us() - t0);
 
     t0 = now_us();
-    if (pthreads > 256) pthreads = 256;
     pthread_t th[256];
     worker w[256];
     /* one page-locked allocation for all threads' blocks (page-locking is slow per call) */
     float *pinned = NULL;
     const size_t thread_floats = (size_t)S.n * S.block_points * 3;
-    if (size && pc_host_alloc((void **)&pinned, (uint64_t)pthreads * thread_floats * 4) != PC_OK) {
+    if (size && !S.queued && pc_host_alloc((void **)&pinned, (uint64_t)pthreads * thread_floats * 4) != PC_OK) {
         fprintf(stderr, "pc_host_alloc: %s\n", pc_last_error());
         return -1;
     }
@@ -350,7 +476,7 @@ int main(int argc, char **argv)
         if (w[t].status == 1) { perror(w[t].msg); exit(-1); }
         if (w[t].status == 2) { fprintf(stderr, "pc_append: %s\n", w[t].msg); exit(-1); }
     }
-    pc_host_free(pinned);
+    if (pinned) pc_host_free(pinned);
     close(fd);
     if (mapped) munmap(file, size);
     else free(file);
@@ -366,14 +492,36 @@ int main(int argc, char **argv)
        fold of the counter threads' totals (main.c:231) */
     static finisher fin[MAX_SLABS];
     pthread_t fth[MAX_SLABS];
-    for (int s = 0; s < S.n; s++) {
+    static uint64_t held[MAX_SLABS];
+    static int order[MAX_SLABS], taken_by[MAX_SLABS];
+    static double busy_us[MAX_SLABS];
+    static taker tk[MAX_SLABS];
+    atomic_int next = 0, failed = 0;
+    if (S.queued) {
+        for (int s = 0; s < S.n; s++) {
+            order[s] = s;
+            for (int t = 0; t < pthreads; t++) held[s] += w[t].held_points[s];
+        }
+        for (int a = 1; a < S.n; a++)                  /* most points first: the long jobs start early */
+            for (int b = a; b > 0 && held[order[b]] > held[order[b - 1]]; b--) {
+                const int o = order[b]; order[b] = order[b - 1]; order[b - 1] = o;
+            }
+        for (int g = 0; g < S.gpus; g++) {
+            tk[g] = (taker){.slabs = &S, .w = w, .nt = pthreads, .order = order, .points = held, .next = &next,
+                            .failed = &failed, .g = g, .fin = fin, .taken_by = taken_by, .busy_us = busy_us};
+            if (pthread_create(&fth[g], NULL, taker_thread, &tk[g]) != 0) { perror("pthread_create"); exit(-1); }
+        }
+        for (int g = 0; g < S.gpus; g++)
+            if (pthread_join(fth[g], NULL) != 0) { perror("pthread_join"); exit(-1); }
+    }
+    for (int s = 0; s < S.n && !S.queued; s++) {
         fin[s].ctx = S.ctx[s];
         if (S.n == 1) finish_thread(&fin[s]);
         else if (pthread_create(&fth[s], NULL, finish_thread, &fin[s]) != 0) { perror("pthread_create"); exit(-1); }
     }
     int64_t npairs = 0, tests = 0;
     float ms[2] = {0, 0};
-    for (int s = 0; s < S.n && S.n > 1; s++)          /* all of them, before any result is judged: no thread may */
+    for (int s = 0; s < S.n && S.n > 1 && !S.queued; s++)   /* all of them, before any result is judged: no thread may */
         if (pthread_join(fth[s], NULL) != 0) { perror("pthread_join"); exit(-1); }   /* still be inside HIP at exit */
     for (int s = 0; s < S.n; s++) {
         if (fin[s].rc != PC_OK) {
@@ -390,14 +538,17 @@ int main(int argc, char **argv)
         fprintf(stderr, "%16s:  %10.0f us\n", "count", ms[1] * 1e3);
         fprintf(stderr, "%16s:  %10.0f us\n", "finish(wall)", now_us() - t0);
         fprintf(stderr, "%16s:  %10ld\n", "tests", (long)tests);
-        if (S.n > 1)
-            for (int s = 0; s < S.n; s++) {
-                uint64_t held = 0;
-                pc_size(S.ctx[s], &held);
-                fprintf(stderr, "   slab %2d gpu %2d layers [%3d,%3d): %10lu points, binning %8.0f us, count %8.0f us\n", s,
-                        S.device[s], S.cut[s], S.cut[s + 1], (unsigned long)held, fin[s].ms[0] * 1e3, fin[s].ms[1] * 1e3);
-            }
+        for (int s = 0; s < S.n && S.n > 1; s++) {
+            uint64_t in_slab = held[s];
+            if (!S.queued) pc_size(S.ctx[s], &in_slab);
+            fprintf(stderr, "   slab %2d gpu %2d layers [%3d,%3d): %10lu points, binning %8.0f us, count %8.0f us\n", s,
+                    S.device[S.queued ? taken_by[s] : s], S.cut[s], S.cut[s + 1], (unsigned long)in_slab,
+                    fin[s].ms[0] * 1e3, fin[s].ms[1] * 1e3);
+        }
+        for (int g = 0; g < S.gpus && S.queued; g++)
+            fprintf(stderr, "   taker %2d gpu %2d: busy %10.0f us (create %.0f, append %.0f, finish %.0f, destroy %.0f)\n", g,
+                    S.device[g], busy_us[g], tk[g].part_us[0], tk[g].part_us[1], tk[g].part_us[2], tk[g].part_us[3]);
     }
-    for (int s = 0; s < S.n; s++) pc_destroy(S.ctx[s]);
+    for (int s = 0; s < S.n && !S.queued; s++) pc_destroy(S.ctx[s]);
     return 0;
 }

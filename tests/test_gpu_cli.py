@@ -101,6 +101,43 @@ def test_main_multi_gpu_slabs(ht, oracle, golden_dir, tmp_path):
         assert r.returncode == 255 and "domain" in r.stderr
 
 
+def test_main_slab_queue(ht, oracle, golden_dir, tmp_path):
+    """PAIRCOUNT_QUEUE=K: K slabs wait in host memory and the GPU threads (here 1, 2 and 3 of them on GPU 0)
+    take them from a shared cursor.  The golden counts, the oracle's count on clustered points, every slab
+    reported once with the taker that counted it, and a domain error still an error."""
+    with open(os.path.join(golden_dir, "counts.json")) as f:
+        counts = json.load(f)
+    for name, info in counts.items():
+        for g, k, extra in (("1", "2", {}), ("2", "7", {}), ("3", "3", {"PAIRCOUNT_CUTS": "0,199,201,400"}), ("2", "64", {})):
+            env = dict(os.environ, PAIRCOUNT_DEVICES=",".join("0" * int(g)), PAIRCOUNT_QUEUE=k, **extra)
+            r = subprocess.run([ht.MAIN_PATH, "-f", os.path.join(golden_dir, name), "-p", "5", "-g", g],
+                               capture_output=True, text=True, timeout=120, env=env)
+            assert r.returncode == 0, (name, g, k, r.stderr)
+            assert r.stdout == "%d\n" % info["count"], (name, g, k, r.stdout)
+    pts = ht.generate(ht.BLOBS, 12, 700_000, 200_000)
+    want, tests = oracle.count_pairs(pts)
+    binp = str(tmp_path / "b700k.f32")
+    pts.tofile(binp)
+    path = str(tmp_path / "b700k.xyz")
+    ht.generate_text(path, ht.BLOBS, 12, 700_000, 200_000)
+    for f in (path, binp):
+        env = dict(os.environ, PAIRCOUNT_DEVICES="0,0", PAIRCOUNT_QUEUE="16", PAIRCOUNT_TIMER="1")
+        r = subprocess.run([ht.MAIN_PATH, "-f", f, "-p", "8", "-g", "2"], capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 0, r.stderr
+        assert int(r.stdout) == want and want > 0
+        assert str(tests) in r.stderr and r.stderr.count("slab") == 16 and r.stderr.count("taker") == 2
+    far = pts[:1000].copy()
+    far[500, 1] = -10.5
+    fp = str(tmp_path / "far.f32")
+    far.tofile(fp)
+    r = subprocess.run([ht.MAIN_PATH, "-f", fp, "-g", "2"], capture_output=True, text=True, timeout=60,
+                       env=dict(os.environ, PAIRCOUNT_DEVICES="0,0", PAIRCOUNT_QUEUE="5"))
+    assert r.returncode == 255 and "domain" in r.stderr
+    r = subprocess.run([ht.MAIN_PATH, "-f", binp, "-g", "4"], capture_output=True, text=True, timeout=60,
+                       env=dict(os.environ, PAIRCOUNT_QUEUE="3"))
+    assert r.returncode == 255 and "PAIRCOUNT_QUEUE" in r.stderr
+
+
 def test_main_error_statuses_of_the_reference(ht, tmp_path):
     """No -f and an empty file fail as the reference does (open: EFAULT; mmap of zero bytes: EINVAL), status 255."""
     r = subprocess.run([ht.MAIN_PATH], capture_output=True, text=True, timeout=60)
