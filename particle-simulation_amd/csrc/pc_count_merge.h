@@ -58,6 +58,9 @@
 #ifndef PC_M_NS8
 #define PC_M_NS8 8
 #endif
+#ifndef PC_M_NS4
+#define PC_M_NS4 8
+#endif
 #ifndef PC_M_G4_MAX
 #define PC_M_G4_MAX 28u                  // longest mean run (slots) that groups of four lanes take
 #endif
@@ -78,6 +81,9 @@ struct alignas(16) pc_merge_lds {
         uint32_t src[PC_M_LEN];
     };
     uint32_t home[PC_M_CAPH + 64 / 2];  // per home particle: slot | end of its run << 16; then one step's worth of dead entries
+#ifdef PC_M_EXP_PAD
+    uint32_t pad[PC_M_EXP_PAD];
+#endif
 };
 
 // one point (12 bytes) per lane from global memory straight into LDS: lane t's x,y,z land in lds_chunk[t]
@@ -116,10 +122,15 @@ __device__ __forceinline__ uint32_t pc_m_test(uint32_t ap, pc_v2f hxy, float hz,
     for (int k = 0; k < NS; k++) {
         pc_m_arrived(a[k]);
         // (dx*dx + dy*dy) + dz*dz, each step rounded separately (no contraction: see build flags)
+#ifdef PC_M_PLAIN
+        const float dx = hxy.x - a[k].x, dy = hxy.y - a[k].y, e = hz - a[k].z;
+        sq[k] = (dx * dx + dy * dy) + e * e;
+#else
         const pc_v2f d = hxy - pc_v2f{a[k].x, a[k].y};
         const float e = hz - a[k].z;
         const pc_v2f dd = d * d;
         sq[k] = (dd.x + dd.y) + e * e;
+#endif
     }
     uint32_t hits = 0;
 #pragma unroll
@@ -132,10 +143,21 @@ template <int G>
 __device__ __forceinline__ uint32_t pc_m_steps(const pc_merge_lds &L, uint32_t nh, uint32_t tot, int lane, float d2max)
 {
     constexpr int H = 64 / G;
-    constexpr int NS0 = G <= 4 ? 8 : G == 8 ? PC_M_NS8 : 4;   // slots per lane before the run's end is looked at (G * NS0 <= 64)
+    constexpr int NS0 = G == 4 ? PC_M_NS4 : G < 4 ? 8 : G == 8 ? PC_M_NS8 : 4;   // slots per lane before the run's end is looked at (G * NS0 <= 64)
     uint32_t hits = 0;
     asm volatile("" : "+v"(lane));                      // per-lane constants are recomputed per window, not kept in registers
-    const uint32_t j = lane & (G - 1), grp = lane / G;
+    const uint32_t j = lane & (G - 1);
+    uint32_t grp = lane / G;
+#ifdef PC_M_QUADPERM
+    // A 16-byte LDS read is served in four groups of 16 lanes, quads (lane / 4) {0,3,5,6} {1,2,4,7} {8,11,13,14}
+    // {9,10,12,15}; two lanes of a group collide when their slots lie a multiple of 16 apart.  Neighbouring
+    // home particles sit a few slots apart, so the quads of one group take neighbouring home particles.
+    if (G <= 4) {
+        const uint32_t quad = lane >> 2;
+        const uint32_t pq = ((0x73261540u >> (4 * (quad & 7))) & 7u) | (quad & 8u);
+        grp = pq * (4 / G) + ((lane / G) & (4 / G - 1));
+    }
+#endif
     nh = __builtin_amdgcn_readfirstlane(nh);
     tot = __builtin_amdgcn_readfirstlane(tot);
     const uint32_t pt_lds = pc_lds_addr(L.pt);
@@ -148,6 +170,14 @@ __device__ __forceinline__ uint32_t pc_m_steps(const pc_merge_lds &L, uint32_t n
         uint32_t p = q + 1 + j;                          // the lane's first slot
         int rem = (int)(e >> 16) - (int)p;                // slots from there to the end of the run
         hits += pc_m_test<G, NS0>(pt_lds + 16 * p, hxy, hz, d2max);
+#ifdef PC_M_EXP_EXTRA_VALU
+        {   // experiment: extra independent vector instructions per step
+            uint32_t w = p;
+#pragma unroll
+            for (int x = 0; x < PC_M_EXP_EXTRA_VALU; x++) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(w) : "v"(q));
+            asm volatile("" :: "v"(w));
+        }
+#endif
         rem -= G * NS0;
         p += G * NS0;
         while (__builtin_amdgcn_ballot_w64(rem > 0) != 0) {
