@@ -46,20 +46,18 @@
 #include "pc_count_group.h"
 
 #ifndef PC_M_CAP
-#define PC_M_CAP 384                    // slots of a window's blocks (even)
+#define PC_M_CAP 376                    // slots of a window's blocks (even)
 #endif
 #define PC_M_CAPH 160                   // home particles of a window
-#define PC_M_SLACK 80                   // never-matching slots behind the last block: a lane's first pass reads at most 65 past it
-#define PC_M_LEN (PC_M_CAP + PC_M_SLACK)
+#define PC_M_REACH 32                   // a lane's pass reads at most this many slots past the first slot of its group
+#ifndef PC_M_SLACK
+#define PC_M_SLACK 40                   // never-matching slots behind the last block (more than PC_M_REACH, at most 64)
+#endif
+#define PC_M_LEN (PC_M_CAP + PC_M_SLACK) // 416 slots = 6656 bytes: six waves per SIMD fit the CU's 160 KB
+#define PC_M_HOME0 96                   // the list of home particles lies in the unused fourth words of slots 96 ...
 #define PC_M_MAX_G 16
 #ifndef PC_M_MAX_RUN
 #define PC_M_MAX_RUN 130u                 // longest mean run (slots) this kernel takes
-#endif
-#ifndef PC_M_NS8
-#define PC_M_NS8 8
-#endif
-#ifndef PC_M_NS4
-#define PC_M_NS4 8
 #endif
 #ifndef PC_M_G4_MAX
 #define PC_M_G4_MAX 28u                  // longest mean run (slots) that groups of four lanes take
@@ -74,13 +72,20 @@
 // the copy runs from the last chunk of 64 slots to the first, so a chunk's 1024 bytes never reach the
 // 256-byte list pieces of the chunks still to come.
 typedef float pc_v4f __attribute__((ext_vector_type(4)));
+#define PC_M_SPARE (4 * (PC_M_HOME0 - 1))
+static_assert(PC_M_CAP <= PC_M_SPARE, "the gather list must end before the spare word and the list of home particles");
+static_assert(PC_M_HOME0 + PC_M_CAPH + 32 <= PC_M_LEN, "the list of home particles must fit the slot array");
+static_assert(PC_M_SLACK > PC_M_REACH && PC_M_SLACK <= 64, "slack");
 
 struct alignas(16) pc_merge_lds {
     union {
         pc_v4f pt[PC_M_LEN];
-        uint32_t src[PC_M_LEN];
+        uint32_t src[4 * PC_M_LEN];     // words 0 .. PC_M_CAP-1: the gather list; word PC_M_SPARE: writes of lanes with nothing to write
     };
-    uint32_t home[PC_M_CAPH + 64 / 2];  // per home particle: slot | end of its run << 16; then one step's worth of dead entries
+    // entry h of the list of home particles (slot | end of its run << 16; behind the last one a step's worth of
+    // dead entries): the fourth word of slot PC_M_HOME0 + h, which neither the copy nor the gather list touches
+    __device__ __forceinline__ uint32_t &home(uint32_t h) { return src[4 * (PC_M_HOME0 + h) + 3]; }
+    __device__ __forceinline__ const uint32_t &home(uint32_t h) const { return src[4 * (PC_M_HOME0 + h) + 3]; }
 #ifdef PC_M_EXP_PAD
     uint32_t pad[PC_M_EXP_PAD];
 #endif
@@ -143,7 +148,9 @@ template <int G>
 __device__ __forceinline__ uint32_t pc_m_steps(const pc_merge_lds &L, uint32_t nh, uint32_t tot, int lane, float d2max)
 {
     constexpr int H = 64 / G;
-    constexpr int NS0 = G == 4 ? PC_M_NS4 : G < 4 ? 8 : G == 8 ? PC_M_NS8 : 4;   // slots per lane before the run's end is looked at (G * NS0 <= 64)
+    constexpr int NS0 = G <= 4 ? 8 : PC_M_REACH / G;   // slots per lane before the run's end is looked at
+    constexpr int NST = G == 8 ? 4 : 2;                // and per turn of the loop after that
+    static_assert(G * NS0 <= PC_M_REACH && G * NST <= PC_M_REACH, "reads must stay inside the never-matching slots");
     uint32_t hits = 0;
     asm volatile("" : "+v"(lane));                      // per-lane constants are recomputed per window, not kept in registers
     const uint32_t j = lane & (G - 1);
@@ -162,7 +169,7 @@ __device__ __forceinline__ uint32_t pc_m_steps(const pc_merge_lds &L, uint32_t n
     tot = __builtin_amdgcn_readfirstlane(tot);
     const uint32_t pt_lds = pc_lds_addr(L.pt);
     for (uint32_t base = 0; base < nh; base += H) {
-        const uint32_t e = L.home[base + grp];           // past nh: dead entries (a NaN slot, an empty run)
+        const uint32_t e = L.home(base + grp);           // past nh: dead entries (a NaN slot, an empty run)
         const uint32_t q = e & 0xFFFFu;
         const pc_v4f h = L.pt[q];
         const pc_v2f hxy = {h.x, h.y};
@@ -170,21 +177,13 @@ __device__ __forceinline__ uint32_t pc_m_steps(const pc_merge_lds &L, uint32_t n
         uint32_t p = q + 1 + j;                          // the lane's first slot
         int rem = (int)(e >> 16) - (int)p;                // slots from there to the end of the run
         hits += pc_m_test<G, NS0>(pt_lds + 16 * p, hxy, hz, d2max);
-#ifdef PC_M_EXP_EXTRA_VALU
-        {   // experiment: extra independent vector instructions per step
-            uint32_t w = p;
-#pragma unroll
-            for (int x = 0; x < PC_M_EXP_EXTRA_VALU; x++) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(w) : "v"(q));
-            asm volatile("" :: "v"(w));
-        }
-#endif
         rem -= G * NS0;
         p += G * NS0;
         while (__builtin_amdgcn_ballot_w64(rem > 0) != 0) {
             p = min(p, tot);                              // finished lanes wait on the never-matching slots
-            hits += pc_m_test<G, 2>(pt_lds + 16 * p, hxy, hz, d2max);
-            rem -= 2 * G;
-            p += 2 * G;
+            hits += pc_m_test<G, NST>(pt_lds + 16 * p, hxy, hz, d2max);
+            rem -= NST * G;
+            p += NST * G;
         }
     }
     return hits;    // wave-uniform
@@ -212,7 +211,10 @@ __device__ __forceinline__ unsigned long long pc_m_defer(const float *__restrict
     return acc;
 }
 
-__global__ void __launch_bounds__(64, 6)
+#ifndef PC_M_WAVES
+#define PC_M_WAVES 6                    // per SIMD: what the slot array and 80 registers allow
+#endif
+__global__ void __launch_bounds__(64, PC_M_WAVES)
 pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T, int x_lo, int x_hi,
                    unsigned int *__restrict__ queue, uint32_t seg_cap, int gate, uint32_t gate_limit,
                    unsigned long long *__restrict__ out, const pc_geom geo)
@@ -316,15 +318,15 @@ pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T
                 {
                     const uint32_t nhome = lane < w ? n[0] : 0u;
                     const uint32_t ent = ex | (end2 << 16);
-                    const uint32_t spare = PC_M_LEN - 1;                  // last word of the list: never a slot's entry
+                    const uint32_t spare = PC_M_SPARE;
 #pragma unroll
                     for (uint32_t v = 0; v < PC_M_UNROLL; v++) {
                         L.src[v < n[0] ? ex + v : spare] = 12u * (s[0] + v);
-                        L.home[v < nhome ? exh + v : PC_M_CAPH + 31] = ent + v;
+                        L.home(v < nhome ? exh + v : PC_M_CAPH + 31) = ent + v;
                     }
                     for (uint32_t v = PC_M_UNROLL; __builtin_amdgcn_ballot_w64(v < n[0]) != 0; v++) {
                         if (v < n[0]) L.src[ex + v] = 12u * (s[0] + v);
-                        if (v < nhome) L.home[exh + v] = ent + v;
+                        if (v < nhome) L.home(exh + v) = ent + v;
                     }
                     uint32_t o = ex + n[0];
 #pragma unroll
@@ -336,7 +338,7 @@ pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T
                         o += n[r];
                     }
                     // one step's worth of dead home entries: a slot of the never-matching tail, an empty run
-                    if (lane < 32) L.home[nh + lane] = tot | (tot << 16);
+                    if (lane < 32) L.home(nh + lane) = tot | (tot << 16);
                 }
                 pc_wave_lds_sync();
                 // ---- stage 2, lane = slot: gather the points through the list, straight into LDS (no registers)
@@ -354,8 +356,7 @@ pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T
                     if (64u * c < tot) pc_m_dma_point(bytes + off[c], L.pt + 64 * c);
                 pc_dma_wait();
                 const float never = __builtin_nanf("");
-                L.pt[tot + lane].x = never;
-                if (lane < PC_M_SLACK - 64) L.pt[tot + 64 + lane].x = never;
+                if (lane < PC_M_SLACK) L.pt[tot + lane].x = never;
                 pc_wave_lds_sync();
                 // ---- the tests: group width from the mean run length (three blocks)
                 const uint32_t m3 = 3u * tot, blocks = (uint32_t)nblk;
