@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--bin-variant", type=int, default=None)
     ap.add_argument("--count-variant", type=int, default=None)
+    ap.add_argument("--lib", default=None, help="another build of libpaircount.so (A/B experiments)")
     ap.add_argument("--as-rank", type=int, nargs=2, metavar=("R", "W"), default=None,
                     help="the slab rank R of W would hold (equal cuts; weak-scaling workloads use W times the points)")
     args = ap.parse_args()
@@ -28,6 +29,9 @@ def main():
     from __graft_entry__ import load_package
     import bench
     psa = load_package()
+    if args.lib:
+        psa.LIB_PATH = os.path.abspath(args.lib)
+        psa._lib = None
     ht = importlib.import_module("particle_simulation_amd.hosttools")
     kind_name, points, sigma, _ = bench.WORKLOADS[args.workload]
     kind = ht.UNIFORM if kind_name == "uniform" else ht.BLOBS
