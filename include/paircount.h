@@ -205,8 +205,10 @@ int pc_count_pairs_noalloc(const float *d_xyz, uint64_t n, int x_lo, int x_hi,
    capacity of the pair test's list of heavy-pencil segments (default and
    maximum 262144; 0 = never cut a pencil), or "heavy": the capacity of its list
    of over-full cells' home-particle chunks (default and maximum 65536; 0 = such
-   cells are processed by the wave that meets them).  Returns PC_ERR_ARG for an unknown
-   name or value. */
+   cells are processed by the wave that meets them), or "dense": which kernel works
+   the segment list off after the merged-window pair test (1, the default: the
+   candidates-in-registers kernel; 0: the group kernel).  Returns PC_ERR_ARG for an
+   unknown name or value. */
 int pc_set_variant(const char *name, int value);
 
 /* Per-kernel device timing for the stage functions above: while enabled, a

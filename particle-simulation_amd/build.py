@@ -23,7 +23,9 @@ ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CC = os.environ.get("CC", "gcc")
 
-HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall"] + os.environ.get("PC_EXTRA_FLAGS", "").split()
+# -fno-slp-vectorize: the dense pair test's nine plain instructions per 64 tests must not be re-packed into
+# two-wide instructions with register shuffles (packed binary32 arithmetic is no faster per operation on this part)
+HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-Wall"] + os.environ.get("PC_EXTRA_FLAGS", "").split()
 # x86-64-v3 (AVX2, BMI2, LZCNT): what the tokenizer's bit tricks compile to single instructions on; the
 # host CPUs of MI355X machines all have it.  (The reference builds with -O3 -march=native.)
 C_FLAGS = ["-O3", "-march=x86-64-v3", "-std=c11", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-pthread",

@@ -18,6 +18,7 @@
 #include "pc_count_wave.h"
 #include "pc_count_group.h"
 #include "pc_count_merge.h"
+#include "pc_count_dense.h"
 #include "pc_generate.h"
 
 // ------------------------------------------------------------------ errors --
@@ -123,6 +124,7 @@ static std::atomic<int> g_variant_bin{1};     // 0 = atomic counting sort, 1 = L
 static std::atomic<int> g_variant_count{4};
 static std::atomic<int> g_heavy{PC_G_HEAVY_CAP};    // capacity of the list of over-full cells' home-particle chunks (0: never listed)
 static std::atomic<int> g_segments{PC_G_SEG_CAP};  // capacity of the heavy-pencil segment list (0: pencils are never cut)
+static std::atomic<int> g_dense{1};                // who works the segment list off after the merged-window kernel: 1 = the dense kernel (variant 6), 0 = variant 3's
 
 extern "C" int pc_set_variant(const char *name, int value)
 {
@@ -145,6 +147,11 @@ extern "C" int pc_set_variant(const char *name, int value)
     if (!strcmp(name, "segments")) {
         if (value < 0 || value > PC_G_SEG_CAP) return pc_fail(PC_ERR_ARG, "pc_set_variant: segment capacity %d not in [0,%d]", value, PC_G_SEG_CAP);
         g_segments = value;
+        return PC_OK;
+    }
+    if (!strcmp(name, "dense")) {
+        if (value < 0 || value > 1) return pc_fail(PC_ERR_ARG, "pc_set_variant: dense %d not 0 or 1", value);
+        g_dense = value;
         return PC_OK;
     }
     return pc_fail(PC_ERR_ARG, "pc_set_variant: unknown name '%s'", name);
@@ -586,9 +593,25 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
         }
         const int grid = ((want < most ? want : most) + 7) / 8 * 8;
         if (variant == 5) {
-            PC_LAUNCH("pc_c3_count_groups_segments", pc_c3_count_groups<false>, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
-                      d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap, PC_GATE_IF_EVEN, gate_limit,
-                      (unsigned long long *)d_npairs, t_geo.d2max);
+            if (g_dense.load()) {
+                // planned segments and pencil rests: cells filled well enough for the candidates-in-registers form
+                static int resident6_on[64];
+                int r6 = resident6_on[dev];
+                if (!r6) {
+                    int per_cu = 0;
+                    hipDeviceProp_t prop;
+                    PC_HIP(hipGetDeviceProperties(&prop, dev));
+                    PC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pc_c6_count_dense, 64, 0));
+                    r6 = (per_cu > 0 ? per_cu : 16) * prop.multiProcessorCount;
+                    resident6_on[dev] = r6;
+                }
+                PC_LAUNCH("pc_c6_count_dense", pc_c6_count_dense, dim3(r6), dim3(64), (hipStream_t)stream,
+                          d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap, PC_GATE_IF_EVEN, gate_limit,
+                          (unsigned long long *)d_npairs, t_geo.d2max);
+            } else
+                PC_LAUNCH("pc_c3_count_groups_segments", pc_c3_count_groups<false>, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
+                          d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap, PC_GATE_IF_EVEN, gate_limit,
+                          (unsigned long long *)d_npairs, t_geo.d2max);
             PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups<true>, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
                       d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap, PC_GATE_IF_CLUSTERED, gate_limit,
                       (unsigned long long *)d_npairs, t_geo.d2max);

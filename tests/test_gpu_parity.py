@@ -28,9 +28,11 @@ def default_variants(psa):
     """Every test starts and ends on the library's default kernels."""
     psa.set_variant("bin", 1)
     psa.set_variant("count", 4)
+    psa.set_variant("dense", 1)
     yield
     psa.set_variant("bin", 1)
     psa.set_variant("count", 4)
+    psa.set_variant("dense", 1)
 
 
 def dev(torch_mod, a):
@@ -404,6 +406,46 @@ def test_density_regimes(psa, stages, torch_mod, oracle, shape):
     for bv, cv in VARIANTS:
         got, tests, _ = gpu_count(psa, stages, torch_mod, xyz, bin_v=bv, count_v=cv)
         assert got == want, (shape, bv, cv)
+        assert tests == want_tests
+
+
+@pytest.mark.parametrize("shape", ["filled_slab", "pencil_100", "one_cell_700", "ragged", "face_pencils", "over_full"])
+def test_dense_segment_kernel(psa, stages, torch_mod, oracle, shape):
+    """The segments of cut pencils are worked off by the dense kernel (candidates in registers) or, with
+    pc_set_variant("dense", 0), by the group kernel: same count as the oracle either way.  The shapes cover one
+    chunk of home particles and one piece of candidates (the usual case), several of each (more than 64 points in
+    a cell, more than 256 candidates), empty cells inside a segment, pencils at the faces of the grid (missing
+    rows), and cells handed on to the over-full-cell kernel."""
+    rng = np.random.default_rng(sum(shape.encode()))
+    if shape == "filled_slab":             # 16 points per cell in a 2 x 40 x 400 block: every pencil is cut into segments
+        xyz = _cell_box(rng, 2 * 40 * 400 * 16, (30, 100, 0), (32, 140, 400))
+    elif shape == "pencil_100":            # ~100 per cell: two chunks of home particles, several pieces of candidates
+        xyz = np.concatenate([_cell_box(rng, 40_000, (200, 200, 0), (201, 201, 400)),
+                              _cell_box(rng, 40_000, (201, 199, 0), (202, 202, 400))])
+    elif shape == "one_cell_700":          # a cell of 700 points (11 chunks of home particles) inside a filled pencil
+        xyz = np.concatenate([_cell_box(rng, 8_000, (77, 77, 0), (78, 78, 400)),
+                              _cell_box(rng, 700, (77, 77, 200), (78, 78, 201)),
+                              _cell_box(rng, 300, (78, 78, 199), (79, 79, 202))])
+    elif shape == "ragged":                # occupancy from 0 to ~250 per cell with empty stretches
+        z = np.sqrt(rng.uniform(0, 1, 120_000)) * 19.9 - 9.95
+        z = z[(np.floor((z + 10) / 0.05).astype(int) % 7) != 3]
+        xy = _cell_box(rng, len(z), (100, 100, 0), (103, 103, 1))[:, :2]
+        xyz = np.column_stack([xy, z])
+    elif shape == "face_pencils":          # pencils on the y = 0, y = 399 and x = 399 faces: rows outside the grid
+        xyz = np.concatenate([_cell_box(rng, 12_000, (10, 0, 0), (11, 2, 400)),
+                              _cell_box(rng, 12_000, (10, 398, 0), (11, 400, 400)),
+                              _cell_box(rng, 12_000, (399, 0, 0), (400, 1, 400)),
+                              _cell_box(rng, 12_000, (399, 399, 0), (400, 400, 400))])
+    else:                                  # cells whose home particles x candidates pass the over-full limit
+        xyz = np.concatenate([_cell_box(rng, 6_000, (120, 77, 301), (121, 78, 302)),
+                              _cell_box(rng, 4_000, (120, 77, 302), (121, 78, 303)),
+                              _cell_box(rng, 20_000, (120, 77, 0), (121, 78, 400))])
+    xyz = xyz.astype(np.float32)
+    want, want_tests = oracle.count_pairs(xyz)
+    for dense in (1, 0):
+        psa.set_variant("dense", dense)
+        got, tests, _ = gpu_count(psa, stages, torch_mod, xyz, bin_v=1, count_v=5)
+        assert got == want, (shape, dense)
         assert tests == want_tests
 
 
