@@ -1,1 +1,2 @@
-for l in dense dense48 dense47 dense57; do echo "== $l"; timeout -k 10 200 python3 tools/dense_probe.py --lib exp/lib_$l.so --points 125000000 --rank 3 8 --reps 5 2>&1 | grep "dense=1" | tail -1; done
+timeout -k 10 200 python3 tools/exp_libs.py --workload blobs100m --reps 5 --kernels exp/lib_even.so 2>&1 | grep -v "l[1-7]\|amdgpu"
+PC_EXP_EVEN=1 timeout -k 10 200 python3 tools/exp_libs.py --workload blobs100m --reps 5 --kernels exp/lib_even.so 2>&1 | grep -v "l[1-7]\|amdgpu"
