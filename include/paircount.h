@@ -78,14 +78,19 @@ int pc_create(pc_context **ctx, int device, uint64_t expected_points);
 int pc_set_slab(pc_context *ctx, int x_lo, int x_hi);
 
 /* Gives the context another geometry than the reference's (any time before
-   pc_finish).  PC_ERR_ARG for values outside the requirements above. */
+   pc_finish; best before the first append: blocks appended earlier were
+   pre-counted under the old geometry and pc_finish then counts them again).
+   PC_ERR_ARG for values outside the requirements above. */
 int pc_set_geometry(pc_context *ctx, const pc_geometry *g);
 
 /* Replaces the per-point sink insert(hm, key, val) (hashmap.h:33,94; called
    from every parser thread at main.c:137).  Appends n points given as packed
    float x,y,z triples in HOST memory.  Thread-safe: parser threads call it
    concurrently, each with its own buffer; the data is copied before return.
-   The cell key (main.c:134-136) is computed by the library on the GPU. */
+   The cell key (main.c:134-136) is computed by the library on the GPU; the
+   first pass of the binning (the histogram of x layers) is queued on the GPU
+   for each block as it arrives, behind its copy, so that it runs while the
+   producers work on their next blocks and pc_finish starts from its result. */
 int pc_append(pc_context *ctx, const float *xyz, uint64_t n);
 
 /* Page-locked host memory for the blocks handed to pc_append: the copy is then

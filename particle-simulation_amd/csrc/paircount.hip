@@ -321,14 +321,17 @@ static pc_lds_ws carve_lds_ws(void *ws, uint64_t n)
 }
 
 // layers [layer_lo, layer_hi] get their pencils sorted and their table slices written (all: 0 .. PC_NBB-1)
+// (layer_counts: the [NREP][404] counts of L1 if they were taken while the points arrived, else null)
 static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *table, void *ws,
-                   int32_t *d_status, hipStream_t s, int layer_lo, int layer_hi)
+                   int32_t *d_status, hipStream_t s, int layer_lo, int layer_hi, const uint32_t *layer_counts = nullptr)
 {
     pc_lds_ws w = carve_lds_ws(ws, n);
     PC_HIP(hipMemsetAsync(w.layer_count, 0, (PC_L_NREP * PC_L_BINS + PC_L_NREP * PC_L_PSTRIDE + 8) * sizeof(uint32_t), s));
     const int tiles = (int)((n + PC_L_TILE - 1) / PC_L_TILE);
-    if (n) PC_LAUNCH("pc_l1_hist_x", pc_l1_hist_x, dim3(grid_for(n, PC_L_TILE, 2048)), dim3(PC_L_TPB), s,
-                     d_xyz, n, w.layer_count, d_status, t_geo);
+    if (layer_counts)
+        PC_HIP(hipMemcpyAsync(w.layer_count, layer_counts, PC_L_NREP * PC_L_BINS * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    else if (n) PC_LAUNCH("pc_l1_hist_x", pc_l1_hist_x, dim3(grid_for(n, PC_L_TILE, 2048)), dim3(PC_L_TPB), s,
+                          d_xyz, n, w.layer_count, d_status, t_geo);
     PC_LAUNCH("pc_l2_scan_x", pc_l2_scan_x, dim3(1), dim3(512), s, w.layer_count, w.layer_start, w.layer_cursor,
               w.layer_tile, w.tile_layer);
     if (n) {
@@ -438,7 +441,7 @@ extern "C" int pc_cell_keys_device(const float *d_xyz, uint64_t n, uint32_t *d_k
 
 static int bin_layers(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
                       uint32_t *d_cell_start, void *d_workspace, size_t workspace_bytes,
-                      int32_t *d_status, void *stream, int layer_lo, int layer_hi);
+                      int32_t *d_status, void *stream, int layer_lo, int layer_hi, const uint32_t *layer_counts = nullptr);
 
 extern "C" int pc_bin_device(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
                              uint32_t *d_cell_start, void *d_workspace, size_t workspace_bytes,
@@ -452,7 +455,7 @@ extern "C" int pc_bin_device(const float *d_xyz, uint64_t n, float *d_sorted_xyz
 // other layers; a slab's pair test never reads them).
 static int bin_layers(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
                       uint32_t *d_cell_start, void *d_workspace, size_t workspace_bytes,
-                      int32_t *d_status, void *stream, int layer_lo, int layer_hi)
+                      int32_t *d_status, void *stream, int layer_lo, int layer_hi, const uint32_t *layer_counts)
 {
     if (!d_cell_start || !d_status || !d_workspace)
         return pc_fail(PC_ERR_ARG, "pc_bin_device: null pointer");
@@ -462,7 +465,7 @@ static int bin_layers(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
         return pc_fail(PC_ERR_ARG, "pc_bin_device: workspace %zu < %zu bytes", workspace_bytes,
                        pc_workspace_bytes(n));
     hipStream_t s = (hipStream_t)stream;
-    if (g_variant_bin == 1) return bin_lds(d_xyz, n, d_sorted_xyz, d_cell_start, d_workspace, d_status, s, layer_lo, layer_hi);
+    if (g_variant_bin == 1) return bin_lds(d_xyz, n, d_sorted_xyz, d_cell_start, d_workspace, d_status, s, layer_lo, layer_hi, layer_counts);
     const uint64_t m = PC_NCELLS + 2;
     uint32_t *keys = (uint32_t *)d_workspace;
     uint32_t *sums = (uint32_t *)((char *)d_workspace + align_up((size_t)n * 4 + 4, 256));
@@ -741,6 +744,12 @@ struct pc_context {
     int done;                   // pc_finish has run to its end: finish_rc, npairs, ntests, ms are final
     int finish_rc;              // what that pc_finish returned; later calls return it again
     int append_rc;              // first failure of a copy into a reserved range (the range then holds no points)
+    // The x-layer histogram (level X's first pass) is taken block by block as the points arrive, so that
+    // it overlaps the producer's work and pc_finish starts from the scan.  layers_counted stays set while
+    // every appended point has been counted under the context's current geometry.
+    uint32_t *d_layer_count;    // [NREP][404]
+    int32_t *d_status;          // bit 0: a point outside the grid (set by any kernel of the context)
+    int layers_counted;
     char finish_msg[256], append_msg[256];
     int64_t npairs, ntests;
     float ms[2];
@@ -766,11 +775,19 @@ extern "C" int pc_create(pc_context **out, int device, uint64_t expected_points)
     pthread_rwlock_init(&c->lock, NULL);
     pthread_mutex_init(&c->reserve, NULL);
     hipError_t e = hipMalloc((void **)&c->d_xyz, c->cap * 12);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_layer_count, PC_L_NREP * PC_L_BINS * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_status, sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemset(c->d_layer_count, 0, PC_L_NREP * PC_L_BINS * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(c->d_status, 0, sizeof(int32_t));
     if (e != hipSuccess) {
+        if (c->d_xyz) (void)hipFree(c->d_xyz);
+        if (c->d_layer_count) (void)hipFree(c->d_layer_count);
+        if (c->d_status) (void)hipFree(c->d_status);
         free(c);
-        return pc_fail(PC_ERR_NOMEM, "pc_create: hipMalloc(%llu points): %s", (unsigned long long)c->cap,
+        return pc_fail(PC_ERR_NOMEM, "pc_create: hipMalloc(%llu points): %s", (unsigned long long)expected_points,
                        hipGetErrorString(e));
     }
+    c->layers_counted = 1;
     *out = c;
     return PC_OK;
 }
@@ -793,7 +810,10 @@ extern "C" int pc_set_geometry(pc_context *c, const pc_geometry *g)
     if (rc) return rc;
     pthread_rwlock_wrlock(&c->lock);
     if (c->finished) rc = pc_fail(PC_ERR_STATE, "pc_set_geometry after pc_finish");
-    else c->geo = geo;
+    else {
+        c->geo = geo;
+        if (c->size) __atomic_store_n(&c->layers_counted, 0, __ATOMIC_RELAXED);     // points counted under the old geometry: pc_finish counts afresh
+    }
     pthread_rwlock_unlock(&c->lock);
     return rc;
 }
@@ -857,6 +877,20 @@ static int append_failed(pc_context *c, const char *fmt, const char *what)
     return rc;
 }
 
+// Level X's histogram of the block [off, off+n) that has just been copied in (the caller holds the read
+// lock: the array cannot move).  The kernel is queued behind the copy -- on the null stream after a blocking
+// copy, else on the copy's stream -- and nobody waits for it before pc_finish.  Only the default binning takes
+// the counts; a launch failure merely switches the short cut off.
+static void count_layers_of(pc_context *c, uint64_t off, uint64_t n, hipStream_t s)
+{
+    if (!__atomic_load_n(&c->layers_counted, __ATOMIC_RELAXED) || n == 0) return;
+    const uint64_t tiles = (off + n + PC_L_TILE - 1) / PC_L_TILE - off / PC_L_TILE;
+    const unsigned grid = (unsigned)((tiles < 2048 ? tiles : 2048) + PC_L_NREP - 1) / PC_L_NREP * PC_L_NREP;
+    hipLaunchKernelGGL(pc_l1_hist_x_range, dim3(grid), dim3(PC_L_TPB), 0, s, c->d_xyz, off, off + n, c->d_layer_count,
+                       c->d_status, c->geo);
+    if (hipGetLastError() != hipSuccess) __atomic_store_n(&c->layers_counted, 0, __ATOMIC_RELAXED);
+}
+
 extern "C" int pc_append(pc_context *c, const float *xyz, uint64_t n)
 {
     if (!c) return pc_fail(PC_ERR_ARG, "pc_append: null context");
@@ -867,6 +901,7 @@ extern "C" int pc_append(pc_context *c, const float *xyz, uint64_t n)
     int rc = reserve_slots(c, n, &off);
     if (rc) return rc;
     hipError_t e = hipMemcpy(c->d_xyz + 3 * off, xyz, n * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) count_layers_of(c, off, n, nullptr);
     pthread_rwlock_unlock(&c->lock);
     if (e != hipSuccess) return append_failed(c, "pc_append: hipMemcpy: %s", hipGetErrorString(e));
     return PC_OK;
@@ -900,6 +935,7 @@ extern "C" int pc_append_device(pc_context *c, const float *d_xyz, uint64_t n, v
     int rc = reserve_slots(c, n, &off);
     if (rc) return rc;
     hipError_t e = hipMemcpyAsync(c->d_xyz + 3 * off, d_xyz, n * 12, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) count_layers_of(c, off, n, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     pthread_rwlock_unlock(&c->lock);
     if (e != hipSuccess) return append_failed(c, "pc_append_device: copy: %s", hipGetErrorString(e));
@@ -920,7 +956,6 @@ struct finish_bufs {
     uint32_t *table = nullptr;
     void *ws = nullptr;
     uint64_t *res = nullptr;     // [0] pairs, [1] tests
-    int32_t *status = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // binning start/end, pair test start/end
     ~finish_bufs()
     {
@@ -928,7 +963,6 @@ struct finish_bufs {
         if (table) (void)hipFree(table);
         if (ws) (void)hipFree(ws);
         if (res) (void)hipFree(res);
-        if (status) (void)hipFree(status);
         for (auto e : ev) if (e) (void)hipEventDestroy(e);
     }
 };
@@ -951,8 +985,7 @@ static int finish_work(pc_context *c)
     const size_t wsb = pc_workspace_bytes(n);
     if (hipMalloc((void **)&b.sorted, (n ? n : 1) * 12) != hipSuccess ||
         hipMalloc((void **)&b.table, (PC_NCELLS + 2) * 4) != hipSuccess ||
-        hipMalloc(&b.ws, wsb) != hipSuccess || hipMalloc((void **)&b.res, 16) != hipSuccess ||
-        hipMalloc((void **)&b.status, 4) != hipSuccess)
+        hipMalloc(&b.ws, wsb) != hipSuccess || hipMalloc((void **)&b.res, 16) != hipSuccess)
         return pc_fail(PC_ERR_NOMEM, "pc_finish: device allocation failed for %llu points", (unsigned long long)n);
     for (auto &e : b.ev) PC_HIP(hipEventCreate(&e));
     hipStream_t s = nullptr;
@@ -962,16 +995,19 @@ static int finish_work(pc_context *c)
         explicit device_turn(pthread_mutex_t *mm) : m(mm) { pthread_mutex_lock(m); }
         ~device_turn() { pthread_mutex_unlock(m); }
     } turn(&g_finish_lock[c->device & 63]);
+    // the histogram kernels of the appends ran on the null stream or on streams their callers have synchronised
+    // (pc_append_device waits for its copy AND the kernel queued behind it): this stream is ordered behind them
+    const bool counted = c->layers_counted && g_variant_bin == 1;
     PC_HIP(hipMemsetAsync(b.res, 0, 16, s));
-    PC_HIP(hipMemsetAsync(b.status, 0, 4, s));
+    if (!counted) PC_HIP(hipMemsetAsync(c->d_status, 0, 4, s));      // (the counts taken under another geometry may have flagged points)
     PC_HIP(hipEventRecord(b.ev[0], s));
-    int rc = bin_layers(c->d_xyz, n, b.sorted, b.table, b.ws, wsb, b.status, s, c->x_lo,
-                        c->x_hi < PC_NLAYERS ? c->x_hi : PC_NBB - 1);
+    int rc = bin_layers(c->d_xyz, n, b.sorted, b.table, b.ws, wsb, c->d_status, s, c->x_lo,
+                        c->x_hi < PC_NLAYERS ? c->x_hi : PC_NBB - 1, counted ? c->d_layer_count : nullptr);
     if (rc) return rc;
     PC_HIP(hipEventRecord(b.ev[1], s));
     // a point outside the grid leaves the sorted array and the table incomplete: stop before the pair test
     int32_t host_status = 0;
-    PC_HIP(hipMemcpyAsync(&host_status, b.status, 4, hipMemcpyDeviceToHost, s));
+    PC_HIP(hipMemcpyAsync(&host_status, c->d_status, 4, hipMemcpyDeviceToHost, s));
     PC_HIP(hipStreamSynchronize(s));
     if (host_status & 1)
         return pc_fail(PC_ERR_DOMAIN, "a coordinate lies outside the reference's domain (-10,10)");
@@ -1044,7 +1080,11 @@ extern "C" int pc_phase_ms(pc_context *c, float ms[2])
 extern "C" void pc_destroy(pc_context *c)
 {
     if (!c) return;
-    if (hipSetDevice(c->device) == hipSuccess && c->d_xyz) (void)hipFree(c->d_xyz);
+    if (hipSetDevice(c->device) == hipSuccess) {
+        if (c->d_xyz) (void)hipFree(c->d_xyz);
+        if (c->d_layer_count) (void)hipFree(c->d_layer_count);
+        if (c->d_status) (void)hipFree(c->d_status);
+    }
     pthread_rwlock_destroy(&c->lock);
     pthread_mutex_destroy(&c->reserve);
     free(c);

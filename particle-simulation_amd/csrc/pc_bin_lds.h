@@ -95,6 +95,34 @@ pc_l1_hist_x(const float *__restrict__ xyz, uint64_t n, uint32_t *__restrict__ l
     if (bad) atomicOr(status, 1);
 }
 
+// L1 for a range [first, end) of the array, run as the points arrive (streaming interface): the counts
+// of the ranges add up to what pc_l1_hist_x counts over the whole array, replica by replica -- a point's
+// replica is that of its tile in the whole array, so a range may start and end inside a tile.  The grid is
+// a multiple of NREP: workgroup w takes the tiles t0 + w, t0 + w + grid, ..., all of one replica.
+__global__ void __launch_bounds__(PC_L_TPB)
+pc_l1_hist_x_range(const float *__restrict__ xyz, uint64_t first, uint64_t end, uint32_t *__restrict__ layer_count,
+                   int32_t *__restrict__ status, const pc_geom geo)
+{
+    __shared__ uint32_t h[PC_L_BINS];
+    for (int b = threadIdx.x; b < PC_L_BINS; b += PC_L_TPB) h[b] = 0;
+    __syncthreads();
+    bool bad = false;
+    const uint64_t t0 = first / PC_L_TILE, t1 = (end + PC_L_TILE - 1) / PC_L_TILE;
+    for (uint64_t t = t0 + blockIdx.x; t < t1; t += gridDim.x) {
+        const uint64_t lo = max(first, t * PC_L_TILE), hi = min(end, (t + 1) * PC_L_TILE);
+        for (uint64_t p = lo + threadIdx.x; p < hi; p += PC_L_TPB) {
+            const int i = pc_cell_index(xyz[3 * p], geo);
+            if ((unsigned)i < (unsigned)geo.ncell) atomicAdd(&h[i], 1u);
+            else bad = true;
+        }
+    }
+    __syncthreads();
+    uint32_t *mine = layer_count + ((t0 + blockIdx.x) % PC_L_NREP) * PC_L_BINS;
+    for (int b = threadIdx.x; b < 400; b += PC_L_TPB)
+        if (h[b]) atomicAdd(&mine[b], h[b]);
+    if (bad) atomicOr(status, 1);
+}
+
 // ---- L2: scan of the 403 layer counts (one workgroup) ------------------------
 __global__ void __launch_bounds__(512)
 pc_l2_scan_x(const uint32_t *__restrict__ layer_count, uint32_t *__restrict__ layer_start,

@@ -255,6 +255,43 @@ def test_streaming_interface_threads(psa, torch_mod, oracle):
     pc.close()
 
 
+def test_layers_are_counted_as_blocks_arrive(psa, torch_mod, oracle):
+    """The streaming interface takes level X's histogram block by block at pc_append / pc_append_device (blocks
+    start and end inside tiles of 4096 points); pc_finish starts from it.  Same count as the oracle for ragged
+    blocks from host and device memory; a point outside the grid in an early block is still an error at
+    pc_finish; a geometry set after points were appended makes pc_finish count afresh."""
+    rng = np.random.default_rng(81)
+    xyz = np.concatenate([rng.uniform(-9.999, 9.999, (150_000, 3)),
+                          rng.normal(0.0, 0.08, (60_000, 3))]).astype(np.float32)
+    rng.shuffle(xyz)
+    want, want_tests = oracle.count_pairs(xyz)
+    cuts = [0, 1, 4095, 4096, 4097, 12_288, 70_001, 70_002, 131_072, 200_003, len(xyz)]
+    with psa.PairCounter(device=0, expected_points=5000) as pc:
+        for q, (a, b) in enumerate(zip(cuts, cuts[1:])):
+            if q % 3 == 2:
+                pc.append_device(dev(torch_mod, xyz[a:b]))
+            else:
+                pc.append(xyz[a:b])
+        assert pc.finish() == want and pc.tests() == want_tests
+    bad = xyz.copy()
+    bad[100, 0] = 10.5                                  # x outside the grid, first block
+    with psa.PairCounter(device=0, expected_points=len(bad)) as pc:
+        for a, b in zip(cuts, cuts[1:]):
+            pc.append(bad[a:b])
+        with pytest.raises(psa.PairCountError):
+            pc.finish()
+    # geometry after the appends: the counts taken under the default geometry are dropped
+    import ctypes
+    g = psa.Geometry(ncell=399)
+    inner = xyz[(xyz < 9.94).all(axis=1)]
+    want_inner = oracle.count_pairs(inner)[0]
+    with psa.PairCounter(device=0, expected_points=1000) as pc:
+        pc.append(inner[:77_777])
+        psa._check(psa.lib().pc_set_geometry(pc._h, ctypes.byref(g)))
+        pc.append(inner[77_777:])
+        assert pc.finish() == want_inner
+
+
 def test_append_from_page_locked_blocks(psa, torch_mod, oracle):
     """pc_host_alloc / pc_append from several producer threads, each refilling its own
     page-locked block (what the host program's parser threads do)."""
