@@ -30,6 +30,7 @@ extern "C" {
 #define PC_ERR_DOMAIN (-3)  /* a coordinate maps outside cells [0,400) on some axis */
 #define PC_ERR_NOMEM (-4)   /* host or device allocation failed                     */
 #define PC_ERR_STATE (-5)   /* call order violated (append after finish, ...)       */
+#define PC_ERR_TEXT (-6)    /* text the reference's parser exits on (parse.h:35-39,119-122), or a record too long */
 
 /* Grid geometry fixed by the reference: main.c:30-32
    (BBSIZE 0.05, NBB = 403 cells per axis of which 0..399 can be occupied,
@@ -102,6 +103,31 @@ int pc_host_free(void *p);
 /* Same, for points that already live in device memory (copied device to
    device on `stream`, which must be complete before pc_finish). */
 int pc_append_device(pc_context *ctx, const float *d_xyz, uint64_t n, void *stream);
+
+/* The parser threads' whole inner loop -- parse_line + insert, main.c:132-138 --
+   for a block of TEXT in host memory: the block is copied to the GPU and
+   tokenized there with the reference's parse_float / parse_line semantics
+   (parse.h:24-163: truncating conversion, its leading-zero scan, "e-NN"
+   exponents, CRLF), bit for bit, and the points are appended.  The block must
+   start at the first byte of a record and end behind the last byte of one (the
+   split the reference's parser threads make at main.c:109-129); a record is
+   three tokens, ends with bytes in 1..31 and holds none, and is at most 256
+   bytes long.  Thread-safe like pc_append.  *n_points (may be NULL) receives
+   the number of points appended.  PC_ERR_TEXT where the reference would print
+   and exit (no '.' after the first digit, positive decimal exponent). */
+int pc_append_text(pc_context *ctx, const char *text, uint64_t bytes, uint64_t *n_points);
+
+/* The same tokenizer as a stateless stage on device memory: d_text (16-byte
+   aligned, `bytes` long) -> packed float triples in d_xyz (room for `capacity`
+   points), in file order; *d_npoints = records found (also when more than
+   capacity: then nothing past capacity is written and bit 4 of *d_status is set).
+   *d_status is OR-ed with 2 (no '.'), 4 (positive exponent), 8 (record longer
+   than 256 bytes), 16 (capacity); the caller zeroes it.  d_workspace:
+   pc_parse_workspace_bytes(bytes). */
+size_t pc_parse_workspace_bytes(uint64_t bytes);
+int pc_parse_text_device(const char *d_text, uint64_t bytes, float *d_xyz, uint64_t capacity,
+                         uint64_t *d_npoints, int32_t *d_status, void *d_workspace,
+                         size_t workspace_bytes, void *stream);
 
 /* Replaces flatten(hm,&keys,&size) + count(hm,keys,len) (hashmap.h:34,137;
    main.c:236,331-335): bins every appended point and counts the pairs.

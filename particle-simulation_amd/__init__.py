@@ -27,7 +27,7 @@ PC_NCELLS = PC_NBB ** 3
 PC_NLAYERS = 400
 TABLE_LEN = PC_NCELLS + 2
 
-ERR_NAMES = {0: "PC_OK", -1: "PC_ERR_ARG", -2: "PC_ERR_HIP", -3: "PC_ERR_DOMAIN", -4: "PC_ERR_NOMEM", -5: "PC_ERR_STATE"}
+ERR_NAMES = {0: "PC_OK", -1: "PC_ERR_ARG", -2: "PC_ERR_HIP", -3: "PC_ERR_DOMAIN", -4: "PC_ERR_NOMEM", -5: "PC_ERR_STATE", -6: "PC_ERR_TEXT"}
 
 # every symbol include/paircount.h declares: (name, restype, argtypes)
 _c = ctypes
@@ -41,6 +41,9 @@ ABI = [
     ("pc_host_alloc", _i32, [_c.POINTER(_vp), _u64]),
     ("pc_host_free", _i32, [_vp]),
     ("pc_append_device", _i32, [_vp, _vp, _u64, _vp]),
+    ("pc_append_text", _i32, [_vp, _c.c_char_p, _u64, _c.POINTER(_u64)]),
+    ("pc_parse_workspace_bytes", _sz, [_u64]),
+    ("pc_parse_text_device", _i32, [_vp, _u64, _vp, _u64, _vp, _vp, _vp, _sz, _vp]),
     ("pc_finish", _i32, [_vp, _c.POINTER(_c.c_int64)]),
     ("pc_tests", _i32, [_vp, _c.POINTER(_c.c_int64)]),
     ("pc_size", _i32, [_vp, _c.POINTER(_u64)]),
@@ -181,6 +184,12 @@ class PairCounter:
         assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
         n = t.numel() // 3
         _check(lib().pc_append_device(self._h, t.data_ptr(), n, torch.cuda.current_stream(t.device).cuda_stream))
+
+    def append_text(self, data):
+        """A block of "x y z" lines (bytes, whole records): tokenized on the GPU.  Returns the points appended."""
+        n = ctypes.c_uint64()
+        _check(lib().pc_append_text(self._h, data, len(data), ctypes.byref(n)))
+        return n.value
 
     def size(self):
         n = ctypes.c_uint64()
@@ -346,3 +355,21 @@ def count_pairs(xyz, device="cuda:0", x_lo=0, x_hi=PC_NLAYERS):
     st = DeviceStages(xyz.shape[0], device)
     st.count_pairs(xyz, x_lo, x_hi)
     return st.pairs()
+
+
+def parse_text_device(data, device="cuda:0", capacity=None):
+    """Tokenizes text (bytes) on the GPU: returns (float32 tensor [n,3] on the device, records found, status bits)."""
+    import torch
+    raw = torch.frombuffer(bytearray(data) if len(data) else bytearray(1), dtype=torch.uint8)[:len(data)].to(device)
+    if capacity is None:
+        capacity = len(data) // 6 + 1
+    out = torch.empty((capacity, 3), dtype=torch.float32, device=device)
+    count = torch.zeros(1, dtype=torch.int64, device=device)
+    status = torch.zeros(1, dtype=torch.int32, device=device)
+    wsb = lib().pc_parse_workspace_bytes(len(data))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=device)
+    _check(lib().pc_parse_text_device(raw.data_ptr(), len(data), out.data_ptr(), capacity, count.data_ptr(),
+                                      status.data_ptr(), ws.data_ptr(), wsb, torch.cuda.current_stream(out.device).cuda_stream))
+    torch.cuda.synchronize()
+    n = int(count.item())
+    return out[:min(n, capacity)], n, int(status.item())

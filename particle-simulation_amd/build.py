@@ -34,7 +34,7 @@ C_FLAGS = ["-O3", "-march=x86-64-v3", "-std=c11", "-ffp-contract=off", "-fno-fas
 # any encoding suffix (_e32, _e64, _dpp, _sdwa) counts
 FUSED_F32 = re.compile(r"\bv_(pk_)?(fma|fmac|mad|mac|fma_mix|fmamk|fmaak)_(legacy_)?f32")
 # kernels whose only fused operations are the compiler's expansion of 64-bit integer division (exact by construction)
-FUSED_F32_EXEMPT = ("pc_gen_points",)
+FUSED_F32_EXEMPT = ("pc_gen_points", "pc_t2_parse_records")     # (neither holds any binary32 arithmetic of its own)
 FUNC_LABEL = re.compile(r"^(_Z\w+|\w+):\s*(;.*)?$")
 
 

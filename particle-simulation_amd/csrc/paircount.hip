@@ -20,6 +20,7 @@
 #include "pc_count_merge.h"
 #include "pc_count_dense.h"
 #include "pc_generate.h"
+#include "pc_tokenize.h"
 
 // ------------------------------------------------------------------ errors --
 static thread_local char g_err[512] = "";
@@ -732,6 +733,25 @@ extern "C" int pc_count_pairs_noalloc(const float *d_xyz, uint64_t n, int x_lo, 
 }
 
 // --------------------------------------------------------------- streaming --
+#define PC_TEXT_STAGES 64
+// Device buffers of one pc_append_text call (text, tile numbers, record count, status); kept
+// per context in a small pool so that parser threads reuse theirs from block to block.
+struct text_stage {
+    char *d_text;
+    size_t cap;
+    void *d_tiles;
+    size_t tiles_cap;
+    uint64_t *d_count;       // [0] records, then 4 bytes of status
+};
+
+static void text_stage_free(text_stage &t)
+{
+    if (t.d_text) (void)hipFree(t.d_text);
+    if (t.d_tiles) (void)hipFree(t.d_tiles);
+    if (t.d_count) (void)hipFree(t.d_count);
+    t = text_stage{};
+}
+
 struct pc_context {
     int device;
     int x_lo, x_hi;
@@ -747,6 +767,8 @@ struct pc_context {
     // The x-layer histogram (level X's first pass) is taken block by block as the points arrive, so that
     // it overlaps the producer's work and pc_finish starts from the scan.  layers_counted stays set while
     // every appended point has been counted under the context's current geometry.
+    text_stage stages[PC_TEXT_STAGES];   // pool of pc_append_text's device buffers (under `reserve`)
+    int n_stages;
     uint32_t *d_layer_count;    // [NREP][404]
     int32_t *d_status;          // bit 0: a point outside the grid (set by any kernel of the context)
     int layers_counted;
@@ -942,6 +964,145 @@ extern "C" int pc_append_device(pc_context *c, const float *d_xyz, uint64_t n, v
     return PC_OK;
 }
 
+// ---------------------------------------------------------------- tokenizer --
+static constexpr uint64_t tk_tiles(uint64_t bytes) { return (bytes + PC_TK_TILE - 1) / PC_TK_TILE; }
+
+extern "C" size_t pc_parse_workspace_bytes(uint64_t bytes) { return align_up((size_t)tk_tiles(bytes) * 4 + 4, 256); }
+
+// T1 + scan: *d_npoints = records in the text; the workspace then holds every tile's first record number
+static int tk_count(const char *d_text, uint64_t bytes, uint64_t *d_npoints, void *d_workspace, hipStream_t s)
+{
+    const uint64_t tiles = tk_tiles(bytes);
+    PC_LAUNCH("pc_t1_count_records", pc_t1_count_records, dim3((unsigned)tiles), dim3(PC_TK_TPB), s,
+              (const unsigned char *)d_text, bytes, (uint32_t *)d_workspace);
+    PC_LAUNCH("pc_t1_scan_tiles", pc_t1_scan_tiles, dim3(1), dim3(1024), s, (uint32_t *)d_workspace, (uint32_t)tiles,
+              (unsigned long long *)d_npoints);
+    PC_HIP(hipGetLastError());
+    return PC_OK;
+}
+
+static int tk_parse(const char *d_text, uint64_t bytes, float *d_xyz, uint64_t capacity, int32_t *d_status,
+                    const void *d_workspace, hipStream_t s)
+{
+    PC_LAUNCH("pc_t2_parse_records", pc_t2_parse_records, dim3((unsigned)tk_tiles(bytes)), dim3(PC_TK_TPB), s,
+              (const unsigned char *)d_text, bytes, (const uint32_t *)d_workspace, d_xyz, capacity, d_status);
+    PC_HIP(hipGetLastError());
+    return PC_OK;
+}
+
+static int tk_check_args(const char *who, const char *d_text, uint64_t bytes)
+{
+    if (!d_text && bytes) return pc_fail(PC_ERR_ARG, "%s: null text", who);
+    if ((uintptr_t)d_text & 15u) return pc_fail(PC_ERR_ARG, "%s: the text must be 16-byte aligned", who);
+    if (tk_tiles(bytes) > 0x7FFFFFFFull) return pc_fail(PC_ERR_ARG, "%s: more than %llu bytes in one call", who,
+                                                        (unsigned long long)0x7FFFFFFFull * PC_TK_TILE);
+    return PC_OK;
+}
+
+extern "C" int pc_parse_text_device(const char *d_text, uint64_t bytes, float *d_xyz, uint64_t capacity,
+                                    uint64_t *d_npoints, int32_t *d_status, void *d_workspace,
+                                    size_t workspace_bytes, void *stream)
+{
+    if (!d_npoints || !d_status || !d_workspace) return pc_fail(PC_ERR_ARG, "pc_parse_text_device: null pointer");
+    if (!d_xyz && capacity) return pc_fail(PC_ERR_ARG, "pc_parse_text_device: null point array");
+    int rc = tk_check_args("pc_parse_text_device", d_text, bytes);
+    if (rc) return rc;
+    if (workspace_bytes < pc_parse_workspace_bytes(bytes))
+        return pc_fail(PC_ERR_ARG, "pc_parse_text_device: workspace %zu < %zu bytes", workspace_bytes, pc_parse_workspace_bytes(bytes));
+    hipStream_t s = (hipStream_t)stream;
+    if (bytes == 0) {
+        PC_HIP(hipMemsetAsync(d_npoints, 0, 8, s));
+        return PC_OK;
+    }
+    rc = tk_count(d_text, bytes, d_npoints, d_workspace, s);
+    if (rc) return rc;
+    return tk_parse(d_text, bytes, d_xyz, capacity, d_status, d_workspace, s);
+}
+
+static int tk_status_error(int32_t st)
+{
+    if (st & PC_TK_ERR_NODOT) return pc_fail(PC_ERR_TEXT, "Invalid number format: expected '.' after the first digit");
+    if (st & PC_TK_ERR_POSEXP) return pc_fail(PC_ERR_TEXT, "Positive decimal exponents are not supported");
+    if (st & PC_TK_ERR_LONG) return pc_fail(PC_ERR_TEXT, "a record is longer than %d bytes", PC_TK_TAIL);
+    return pc_fail(PC_ERR_TEXT, "tokenizer status %d", (int)st);
+}
+
+extern "C" int pc_append_text(pc_context *c, const char *text, uint64_t bytes, uint64_t *n_points)
+{
+    if (n_points) *n_points = 0;
+    if (!c) return pc_fail(PC_ERR_ARG, "pc_append_text: null context");
+    if (bytes == 0) return PC_OK;
+    if (!text) return pc_fail(PC_ERR_ARG, "pc_append_text: null text");
+    if (tk_tiles(bytes) > 0x7FFFFFFFull) return pc_fail(PC_ERR_ARG, "pc_append_text: block too large");
+    PC_HIP(hipSetDevice(c->device));
+    // a stage from the pool (or a new one), grown to this block
+    text_stage t{};
+    pthread_mutex_lock(&c->reserve);
+    if (c->n_stages) t = c->stages[--c->n_stages];
+    pthread_mutex_unlock(&c->reserve);
+    struct give_back {
+        pc_context *c;
+        text_stage *t;
+        ~give_back()
+        {
+            pthread_mutex_lock(&c->reserve);
+            const bool room = c->n_stages < PC_TEXT_STAGES;
+            if (room) c->stages[c->n_stages++] = *t;
+            pthread_mutex_unlock(&c->reserve);
+            if (!room) text_stage_free(*t);
+        }
+    } back{c, &t};
+    const size_t want_tiles = pc_parse_workspace_bytes(bytes);
+    if (t.cap < bytes) {
+        if (t.d_text) (void)hipFree(t.d_text);
+        t.d_text = nullptr;
+        t.cap = 0;
+        const size_t cap = align_up((size_t)bytes + bytes / 8, 1 << 20);
+        if (hipMalloc((void **)&t.d_text, cap) != hipSuccess) return pc_fail(PC_ERR_NOMEM, "pc_append_text: %zu bytes of device memory", cap);
+        t.cap = cap;
+    }
+    if (t.tiles_cap < want_tiles) {
+        if (t.d_tiles) (void)hipFree(t.d_tiles);
+        t.d_tiles = nullptr;
+        t.tiles_cap = 0;
+        if (hipMalloc(&t.d_tiles, want_tiles * 2) != hipSuccess) return pc_fail(PC_ERR_NOMEM, "pc_append_text: device memory");
+        t.tiles_cap = want_tiles * 2;
+    }
+    if (!t.d_count && hipMalloc((void **)&t.d_count, 16) != hipSuccess) return pc_fail(PC_ERR_NOMEM, "pc_append_text: device memory");
+    hipStream_t s = nullptr;
+    PC_HIP(hipMemcpy(t.d_text, text, bytes, hipMemcpyHostToDevice));
+    PC_HIP(hipMemsetAsync(t.d_count, 0, 16, s));
+    int rc = tk_count(t.d_text, bytes, t.d_count, t.d_tiles, s);
+    if (rc) return rc;
+    uint64_t host_count = 0;
+    PC_HIP(hipMemcpy(&host_count, t.d_count, 8, hipMemcpyDeviceToHost));
+    if (host_count == 0) return PC_OK;
+    uint64_t off;
+    rc = reserve_slots(c, host_count, &off);           // returns with the read lock held
+    if (rc) return rc;
+    int32_t *d_st = reinterpret_cast<int32_t *>(t.d_count + 1);
+    rc = tk_parse(t.d_text, bytes, c->d_xyz + 3 * off, host_count, d_st, t.d_tiles, s);
+    int32_t st = 0;
+    hipError_t e = rc ? hipSuccess : hipMemcpy(&st, d_st, 4, hipMemcpyDeviceToHost);
+    if (!rc && e == hipSuccess && st == 0) count_layers_of(c, off, host_count, s);
+    pthread_rwlock_unlock(&c->lock);
+    // the slots are reserved: whatever went wrong, the context can no longer produce the file's count
+    if (rc) return append_failed(c, "pc_append_text: %s", g_err);
+    if (e != hipSuccess) return append_failed(c, "pc_append_text: hipMemcpy: %s", hipGetErrorString(e));
+    if (st) {
+        const int code = tk_status_error(st);
+        pthread_mutex_lock(&c->reserve);
+        if (!c->append_rc) {
+            c->append_rc = code;
+            snprintf(c->append_msg, sizeof c->append_msg, "%s", g_err);
+        }
+        pthread_mutex_unlock(&c->reserve);
+        return code;
+    }
+    if (n_points) *n_points = host_count;
+    return PC_OK;
+}
+
 extern "C" int pc_size(pc_context *c, uint64_t *n)
 {
     if (!c || !n) return pc_fail(PC_ERR_ARG, "pc_size: null pointer");
@@ -1084,6 +1245,7 @@ extern "C" void pc_destroy(pc_context *c)
         if (c->d_xyz) (void)hipFree(c->d_xyz);
         if (c->d_layer_count) (void)hipFree(c->d_layer_count);
         if (c->d_status) (void)hipFree(c->d_status);
+        for (int i = 0; i < c->n_stages; i++) text_stage_free(c->stages[i]);
     }
     pthread_rwlock_destroy(&c->lock);
     pthread_mutex_destroy(&c->reserve);

@@ -30,6 +30,10 @@
  * That is the reference's hand-out of work to its counter threads (an atomic cursor,
  * main.c:192) one level up: a GPU that got sparse slabs takes more of them, so a
  * clustered input needs no cost model to stay balanced.
+ * PAIRCOUNT_GPU_TOKENIZER=1 (one slab only) leaves the tokenizing to the GPU too: each
+ * parser thread hands its byte range to the library in blocks of whole lines
+ * (pc_append_text: copy, tokenize with the reference's semantics, append) instead of
+ * tokenizing it.
  * With PAIRCOUNT_TIMER=1 in the environment the four phase times the
  * reference's -DTIMER build prints are written to stderr.
  */
@@ -50,6 +54,8 @@
 #include "xyz_parse.h"
 
 #define BLOCK_POINTS 65536
+#define TEXT_BLOCK_BYTES (8u << 20)    /* GPU tokenizer: bytes per pc_append_text call (plus the rest of the last line) ... */
+#define TEXT_LINE_MAX 4096             /* ... which fits the thread's page-locked block if no line is longer than this */
 #define MAX_SLABS 64
 #define LAYERS PC_NLAYERS
 #define CHUNK_POINTS_MIN 4096         /* host-memory chunk of a queued slab: each is one upload, and an */
@@ -104,6 +110,7 @@ typedef struct {
     chunk *held[MAX_SLABS];  /* queued slabs: this thread's chunks, newest first */
     uint64_t held_points[MAX_SLABS];
     int binary;              /* the file holds float triples, not text */
+    int gpu_text;            /* the GPU tokenizes: this thread only cuts its range into blocks of whole lines */
     char msg[256];
 } worker;
 
@@ -199,6 +206,34 @@ static void *parser_thread(void *arg)
     float *block = w->block;
     const char *p, *stop;
     xyz_thread_range(w->file, w->size, w->t, w->nt, &p, &stop);
+    if (w->gpu_text) {
+        while (p < stop) {
+            const char *e = stop;
+            if ((size_t)(stop - p) > TEXT_BLOCK_BYTES) {
+                e = p + TEXT_BLOCK_BYTES;
+                while (e < stop && *e > '\n') e++;         /* to the end of the line, as the thread split does */
+                if (e < stop) e++;
+            }
+            /* through the thread's page-locked block: the upload is then one DMA at the link's rate (a block whose
+               last line runs past the block's room is uploaded from where it lies) */
+            const char *from = p;
+            if ((size_t)(e - p) <= TEXT_BLOCK_BYTES + TEXT_LINE_MAX) {
+                memcpy(block, p, (size_t)(e - p));
+                from = (const char *)block;
+            }
+            const double t = now_us();
+            const int rc = pc_append_text(w->slabs->ctx[0], from, (uint64_t)(e - p), NULL);
+            w->append_us += now_us() - t;
+            if (rc != PC_OK) {
+                w->status = rc == PC_ERR_TEXT ? 1 : 2;
+                if (rc == PC_ERR_TEXT) snprintf(w->msg, sizeof w->msg, strstr(pc_last_error(), "exponent") ? "sci_exp > 0" : "*str != '.'");
+                else snprintf(w->msg, sizeof w->msg, "%s", pc_last_error());
+                return NULL;
+            }
+            p = e;
+        }
+        return NULL;
+    }
     if (w->slabs->n > 1) {
         while (p < stop) {
             int err = 0;
@@ -459,14 +494,16 @@ int main(int argc, char **argv)
     worker w[256];
     /* one page-locked allocation for all threads' blocks (page-locking is slow per call) */
     float *pinned = NULL;
-    const size_t thread_floats = (size_t)S.n * S.block_points * 3;
+    const int gpu_text = !binary && S.n == 1 && !S.queued && getenv("PAIRCOUNT_GPU_TOKENIZER") != NULL;
+    const size_t thread_floats = gpu_text ? (TEXT_BLOCK_BYTES + TEXT_LINE_MAX) / 4 : (size_t)S.n * S.block_points * 3;
     if (size && !S.queued && pc_host_alloc((void **)&pinned, (uint64_t)pthreads * thread_floats * 4) != PC_OK) {
         fprintf(stderr, "pc_host_alloc: %s\n", pc_last_error());
         return -1;
     }
     for (int t = 0; t < pthreads; t++) {
         w[t] = (worker){.file = file, .size = size, .t = t, .nt = pthreads, .slabs = &S, .status = 0,
-                        .block = pinned + (size_t)t * thread_floats, .binary = binary};
+                        .block = pinned + (size_t)t * thread_floats, .binary = binary,
+                        .gpu_text = gpu_text};
         if (size == 0) continue;
         if (pthread_create(&th[t], NULL, parser_thread, &w[t]) != 0) { perror("pthread_create"); exit(-1); }
     }

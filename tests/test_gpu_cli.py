@@ -27,6 +27,32 @@ def test_main_prints_the_reference_count(ht, golden_dir):
             assert r.stdout == "%d\n" % info["count"], (name, p, r.stdout)     # exactly "%ld\n" (main.c:336)
 
 
+def test_main_with_gpu_tokenizer(ht, oracle, golden_dir, tmp_path):
+    """PAIRCOUNT_GPU_TOKENIZER=1: the parser threads hand blocks of whole lines to pc_append_text; same output on the
+    golden files (CRLF, no final newline, 3 and 9 decimals) and on a file large enough for several blocks per thread;
+    text the reference exits on gives its exit status."""
+    env = dict(os.environ, PAIRCOUNT_GPU_TOKENIZER="1")
+    with open(os.path.join(golden_dir, "counts.json")) as f:
+        counts = json.load(f)
+    for name, info in counts.items():
+        for p in ("1", "5"):
+            r = subprocess.run([ht.MAIN_PATH, "-f", os.path.join(golden_dir, name), "-p", p], capture_output=True, text=True,
+                               timeout=120, env=env)
+            assert r.returncode == 0, (name, r.stderr)
+            assert r.stdout == "%d\n" % info["count"], (name, p, r.stdout)
+    path = str(tmp_path / "b4m.xyz")
+    ht.generate_text(path, ht.BLOBS, 9, 4_000_000, 400_000)              # 114 MB: more than one 32 MB block for a thread
+    want = oracle.count_pairs(ht.generate(ht.BLOBS, 9, 4_000_000, 400_000))[0]
+    for p in ("2", "7"):
+        r = subprocess.run([ht.MAIN_PATH, "-f", path, "-p", p], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and int(r.stdout) == want, (p, r.stderr)
+    bad = str(tmp_path / "bad.xyz")
+    with open(bad, "w") as f:
+        f.write("1.000000 2.000000 3.000000\n" * 1000 + "12.5 1.0 1.0\n" + "1.000000 2.000000 3.000000\n" * 1000)
+    r = subprocess.run([ht.MAIN_PATH, "-f", bad, "-p", "3"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 255 and r.stdout == ""
+
+
 def test_main_on_generated_file_with_timer(ht, oracle, tmp_path):
     path = str(tmp_path / "u300k.xyz")
     n = ht.generate_text(path, ht.UNIFORM, 3, 300_000)

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--workload", default="uniform100m")
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--skip-reference", action="store_true", help="time only the product's host program")
+    ap.add_argument("--gpu-tokenizer", action="store_true",
+                    help="also time the host program with PAIRCOUNT_GPU_TOKENIZER=1 (text uploaded and tokenized on the GPU)")
     ap.add_argument("--sidecar", action="store_true",
                     help="also time the host program on the .f32 form of the same points (no tokenizing)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "e2e_full.json"))
@@ -59,6 +61,12 @@ def main():
         out["gpu_host_program"] = {"wall_s": w, "count": int(r.stdout.strip()),
                                    "phases_s": {m.group(1): float(m.group(2)) / 1e6
                                                 for m in re.finditer(r"(\w[\w()]*):\s+(\d+) us", r.stderr)}}
+        if args.gpu_tokenizer:
+            w, r = timed([ht.MAIN_PATH, "-f", path, "-p", str(args.threads)],
+                         env=dict(os.environ, PAIRCOUNT_TIMER="1", PAIRCOUNT_GPU_TOKENIZER="1"))
+            out["gpu_host_program_gpu_tokenizer"] = {
+                "wall_s": w, "count": int(r.stdout.strip()),
+                "phases_s": {m.group(1): float(m.group(2)) / 1e6 for m in re.finditer(r"(\w[\w()]*):\s+(\d+) us", r.stderr)}}
         ref = os.path.join(ROOT, "oracle", "_ref", "main_timer")
         if os.path.exists(ref) and not args.skip_reference:
             w, r = timed([ref, "-f", path, "-p", str(args.threads), "-c", str(args.threads)])
