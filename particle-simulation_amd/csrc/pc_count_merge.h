@@ -41,6 +41,11 @@
 // this one for the planned and the deferred segments only; if the list is full the
 // wave counts the rest of the pencil itself, one lane per home particle, from global
 // memory.  pc_set_variant("count", 5); chosen by density in the default variant 4.
+//
+// Build switches for measurements (none is set in the product build): PC_M_EXP_NOTEST compiles the tests out
+// (what the bookkeeping and the copy cost alone), PC_M_EXP_PAD=<words> pads the LDS (fewer waves per SIMD),
+// PC_M_PLAIN writes the distance with unpacked instructions only, PC_M_NO_QUADPERM takes the lanes' home
+// particles in lane order, PC_M_CAP / PC_M_WAVES / PC_M_MAX_RUN / PC_M_G4_MAX / PC_M_UNROLL resize the kernel.
 #pragma once
 #include "pc_count_global.h"
 #include "pc_count_group.h"
@@ -365,10 +370,12 @@ pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T
                 hits = 0;
                 if (m3 == 0xFFFFFFFFu)
 #endif
-                if (m3 <= 12u * blocks) hits = pc_m_steps<2>(L, nh, tot, lane, geo.d2max);
-                else if (m3 <= PC_M_G4_MAX * blocks) hits = pc_m_steps<4>(L, nh, tot, lane, geo.d2max);
-                else if (m3 <= 60u * blocks) hits = pc_m_steps<8>(L, nh, tot, lane, geo.d2max);
-                else hits = pc_m_steps<16>(L, nh, tot, lane, geo.d2max);
+                {
+                    if (m3 <= 12u * blocks) hits = pc_m_steps<2>(L, nh, tot, lane, geo.d2max);
+                    else if (m3 <= PC_M_G4_MAX * blocks) hits = pc_m_steps<4>(L, nh, tot, lane, geo.d2max);
+                    else if (m3 <= 60u * blocks) hits = pc_m_steps<8>(L, nh, tot, lane, geo.d2max);
+                    else hits = pc_m_steps<16>(L, nh, tot, lane, geo.d2max);
+                }
                 if (lane == 0) acc += hits;
                 pc_wave_lds_sync();
             }
