@@ -30,10 +30,11 @@
  * That is the reference's hand-out of work to its counter threads (an atomic cursor,
  * main.c:192) one level up: a GPU that got sparse slabs takes more of them, so a
  * clustered input needs no cost model to stay balanced.
- * PAIRCOUNT_GPU_TOKENIZER=1 (one slab only) leaves the tokenizing to the GPU too: each
- * parser thread hands its byte range to the library in blocks of whole lines
- * (pc_append_text: copy, tokenize with the reference's semantics, append) instead of
- * tokenizing it.
+ * PAIRCOUNT_GPU_TOKENIZER=K (one slab only) shares the tokenizing with the GPU: the file
+ * is cut into blocks of whole lines that the parser threads draw from a counter; up to K
+ * threads at a time hand theirs to the library as text (pc_append_text: copy, tokenize
+ * with the reference's semantics, append), the others tokenize theirs on the host.  K at
+ * least the thread count leaves all of it to the GPU.
  * With PAIRCOUNT_TIMER=1 in the environment the four phase times the
  * reference's -DTIMER build prints are written to stderr.
  */
@@ -199,41 +200,71 @@ static void append_binary_share(worker *w)
     flush_blocks(w);
 }
 
+/* one slab: the lines of [p, stop) tokenized here, appended in blocks of BLOCK_POINTS points */
+static void tokenize_range(worker *w, const char *p, const char *stop)
+{
+    float *block = w->block;
+    uint64_t n = 0;
+    while (p < stop) {
+        int err = 0;
+        p = xyz_parse_line_bounded(p, w->file + w->size, block + 3 * n, &err);
+        if (err) {
+            w->status = 1;
+            snprintf(w->msg, sizeof w->msg, err == XYZ_ERR_NODOT ? "*str != '.'" : "sci_exp > 0");
+            return;
+        }
+        if (++n == BLOCK_POINTS) {
+            if (append_block(w, 0, block, n) != PC_OK) return;
+            n = 0;
+        }
+    }
+    if (n) append_block(w, 0, block, n);
+}
+
+/* PAIRCOUNT_GPU_TOKENIZER=K: the file is cut into blocks of whole lines (the reference's thread split, main.c:109-129,
+   applied with one "thread" per block), the parser threads draw the blocks from a shared counter, and up to K of them
+   at a time send theirs through the GPU tokenizer -- copy into the thread's page-locked block, pc_append_text --
+   while the others tokenize theirs here: the PCIe link and the host cores work side by side. */
+static atomic_size_t g_text_next;
+static size_t g_text_blocks;
+static atomic_int g_gpu_lanes_busy;
+static int g_gpu_lanes;
+
+static void share_text_blocks(worker *w)
+{
+    for (;;) {
+        const size_t b = atomic_fetch_add(&g_text_next, 1);
+        if (b >= g_text_blocks || w->status) return;
+        const char *p, *e;
+        xyz_thread_range(w->file, w->size, (int)b, (int)g_text_blocks, &p, &e);
+        if (p >= e) continue;
+        int lane = 0;
+        if ((size_t)(e - p) <= TEXT_BLOCK_BYTES + TEXT_LINE_MAX) {
+            if (atomic_fetch_add(&g_gpu_lanes_busy, 1) < g_gpu_lanes) lane = 1;
+            else atomic_fetch_sub(&g_gpu_lanes_busy, 1);
+        }
+        if (!lane) { tokenize_range(w, p, e); continue; }
+        memcpy(w->block, p, (size_t)(e - p));               /* page-locked: the upload is one DMA at the link's rate */
+        const double t = now_us();
+        const int rc = pc_append_text(w->slabs->ctx[0], (const char *)w->block, (uint64_t)(e - p), NULL);
+        w->append_us += now_us() - t;
+        atomic_fetch_sub(&g_gpu_lanes_busy, 1);
+        if (rc != PC_OK) {
+            w->status = rc == PC_ERR_TEXT ? 1 : 2;
+            if (rc == PC_ERR_TEXT) snprintf(w->msg, sizeof w->msg, strstr(pc_last_error(), "exponent") ? "sci_exp > 0" : "*str != '.'");
+            else snprintf(w->msg, sizeof w->msg, "%s", pc_last_error());
+            return;
+        }
+    }
+}
+
 static void *parser_thread(void *arg)
 {
     worker *w = (worker *)arg;
     if (w->binary) { append_binary_share(w); return NULL; }
-    float *block = w->block;
+    if (w->gpu_text) { share_text_blocks(w); return NULL; }
     const char *p, *stop;
     xyz_thread_range(w->file, w->size, w->t, w->nt, &p, &stop);
-    if (w->gpu_text) {
-        while (p < stop) {
-            const char *e = stop;
-            if ((size_t)(stop - p) > TEXT_BLOCK_BYTES) {
-                e = p + TEXT_BLOCK_BYTES;
-                while (e < stop && *e > '\n') e++;         /* to the end of the line, as the thread split does */
-                if (e < stop) e++;
-            }
-            /* through the thread's page-locked block: the upload is then one DMA at the link's rate (a block whose
-               last line runs past the block's room is uploaded from where it lies) */
-            const char *from = p;
-            if ((size_t)(e - p) <= TEXT_BLOCK_BYTES + TEXT_LINE_MAX) {
-                memcpy(block, p, (size_t)(e - p));
-                from = (const char *)block;
-            }
-            const double t = now_us();
-            const int rc = pc_append_text(w->slabs->ctx[0], from, (uint64_t)(e - p), NULL);
-            w->append_us += now_us() - t;
-            if (rc != PC_OK) {
-                w->status = rc == PC_ERR_TEXT ? 1 : 2;
-                if (rc == PC_ERR_TEXT) snprintf(w->msg, sizeof w->msg, strstr(pc_last_error(), "exponent") ? "sci_exp > 0" : "*str != '.'");
-                else snprintf(w->msg, sizeof w->msg, "%s", pc_last_error());
-                return NULL;
-            }
-            p = e;
-        }
-        return NULL;
-    }
     if (w->slabs->n > 1) {
         while (p < stop) {
             int err = 0;
@@ -249,21 +280,7 @@ static void *parser_thread(void *arg)
         flush_blocks(w);
         return NULL;
     }
-    uint64_t n = 0;
-    while (p < stop) {
-        int err = 0;
-        p = xyz_parse_line_bounded(p, w->file + w->size, block + 3 * n, &err);
-        if (err) {
-            w->status = 1;
-            snprintf(w->msg, sizeof w->msg, err == XYZ_ERR_NODOT ? "*str != '.'" : "sci_exp > 0");
-            break;
-        }
-        if (++n == BLOCK_POINTS) {
-            if (append_block(w, 0, block, n) != PC_OK) break;
-            n = 0;
-        }
-    }
-    if (!w->status && n) append_block(w, 0, block, n);
+    tokenize_range(w, p, stop);
     return NULL;
 }
 
@@ -494,7 +511,13 @@ int main(int argc, char **argv)
     worker w[256];
     /* one page-locked allocation for all threads' blocks (page-locking is slow per call) */
     float *pinned = NULL;
-    const int gpu_text = !binary && S.n == 1 && !S.queued && getenv("PAIRCOUNT_GPU_TOKENIZER") != NULL;
+    const int gpu_text = !binary && S.n == 1 && !S.queued && getenv("PAIRCOUNT_GPU_TOKENIZER") != NULL &&
+                         atoi(getenv("PAIRCOUNT_GPU_TOKENIZER")) > 0;
+    if (gpu_text) {
+        g_gpu_lanes = atoi(getenv("PAIRCOUNT_GPU_TOKENIZER"));
+        g_text_blocks = (size + TEXT_BLOCK_BYTES - 1) / TEXT_BLOCK_BYTES;
+        if (g_text_blocks > 0x7FFFFFFF) g_text_blocks = 0x7FFFFFFF;
+    }
     const size_t thread_floats = gpu_text ? (TEXT_BLOCK_BYTES + TEXT_LINE_MAX) / 4 : (size_t)S.n * S.block_points * 3;
     if (size && !S.queued && pc_host_alloc((void **)&pinned, (uint64_t)pthreads * thread_floats * 4) != PC_OK) {
         fprintf(stderr, "pc_host_alloc: %s\n", pc_last_error());

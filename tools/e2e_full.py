@@ -38,8 +38,9 @@ def main():
     ap.add_argument("--workload", default="uniform100m")
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--skip-reference", action="store_true", help="time only the product's host program")
-    ap.add_argument("--gpu-tokenizer", action="store_true",
-                    help="also time the host program with PAIRCOUNT_GPU_TOKENIZER=1 (text uploaded and tokenized on the GPU)")
+    ap.add_argument("--gpu-tokenizer", type=int, nargs="*", default=[],
+                    help="also time the host program with PAIRCOUNT_GPU_TOKENIZER=K for each K given (K threads at a time "
+                         "send their block of text through the GPU tokenizer, the others tokenize on the host)")
     ap.add_argument("--sidecar", action="store_true",
                     help="also time the host program on the .f32 form of the same points (no tokenizing)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "e2e_full.json"))
@@ -61,10 +62,10 @@ def main():
         out["gpu_host_program"] = {"wall_s": w, "count": int(r.stdout.strip()),
                                    "phases_s": {m.group(1): float(m.group(2)) / 1e6
                                                 for m in re.finditer(r"(\w[\w()]*):\s+(\d+) us", r.stderr)}}
-        if args.gpu_tokenizer:
+        for k in args.gpu_tokenizer:
             w, r = timed([ht.MAIN_PATH, "-f", path, "-p", str(args.threads)],
-                         env=dict(os.environ, PAIRCOUNT_TIMER="1", PAIRCOUNT_GPU_TOKENIZER="1"))
-            out["gpu_host_program_gpu_tokenizer"] = {
+                         env=dict(os.environ, PAIRCOUNT_TIMER="1", PAIRCOUNT_GPU_TOKENIZER=str(k)))
+            out["gpu_host_program_gpu_tokenizer_%d" % k] = {
                 "wall_s": w, "count": int(r.stdout.strip()),
                 "phases_s": {m.group(1): float(m.group(2)) / 1e6 for m in re.finditer(r"(\w[\w()]*):\s+(\d+) us", r.stderr)}}
         ref = os.path.join(ROOT, "oracle", "_ref", "main_timer")
