@@ -553,7 +553,7 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
         if (rc2) return rc2;
         const uint32_t seg_cap = (uint32_t)g_segments.load(), heavy_cap = (uint32_t)g_heavy.load();   // one read each per call
         PC_HIP(hipMemsetAsync(queue, 0, PC_G_FLAGS * sizeof(unsigned int), (hipStream_t)stream));   // all counters
-        const dim3 plan_grid(((x_hi - x_lo) * PC_NLAYERS + 255) / 256);
+        const dim3 plan_grid(((x_hi - x_lo) * PC_NLAYERS + PC_G_PLAN_PENCILS - 1) / PC_G_PLAN_PENCILS);
         // a pencil holding more than four average pencils (and at least 512 points) counts as dense; an input with
         // over a quarter of its points in such pencils is clustered: the merged-window kernel then leaves the
         // whole job to the group kernel, which balances heavy pencils better
@@ -561,7 +561,7 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
         const uint64_t full = 4 * n / slab_pencils;
         const uint32_t full_pencil = (uint32_t)(full < 512 ? 512 : full > 0xFFFFFFFFull ? 0xFFFFFFFFull : full);
         const uint32_t gate_limit = (uint32_t)(n / 4);
-        PC_LAUNCH("pc_c3_plan", pc_c3_plan, plan_grid, dim3(256), (hipStream_t)stream, d_cell_start, x_lo, x_hi, queue,
+        PC_LAUNCH("pc_c3_plan", pc_c3_plan, plan_grid, dim3(PC_G_PLAN_TPB), (hipStream_t)stream, d_cell_start, x_lo, x_hi, queue,
                   seg_cap, full_pencil);
         // as many workgroups as are resident at once (registers and LDS decide: asked of the runtime, once)
         static int resident_on[64];               // per device ordinal (count_queue has checked the range)

@@ -320,64 +320,118 @@ __device__ __forceinline__ uint32_t pc_g_block(const pc_group_lds &L, uint32_t c
     return hits;
 }
 
-// Planning: one thread per home pencil of the slab.  A pencil with many points is
-// cut where the running cost estimate passes PC_G_PLAN_TARGET; its segments are
-// appended to the list (all of them or, if the list is full, none) and its flag
-// tells the pair test to leave the pencil to the segment phase.
-// The walk below either counts the segments of a pencil or writes them from
-// position `slot` on; they always cover the cells [0, 400) exactly.
-template <bool WRITE>
-__device__ __forceinline__ uint32_t pc_plan_walk(const uint32_t *__restrict__ row, uint32_t pencil,
-                                                 unsigned int *__restrict__ work, uint32_t slot, unsigned long long target)
-{
-    uint32_t segs = 0, prev = 0, cur = row[1] - row[0];
-    unsigned long long acc = 0;
-    int z_begin = 0;
-    for (int c = 0; c < PC_NLAYERS; c++) {
-        const uint32_t next = row[c + 2] - row[c + 1];
-        acc += (unsigned long long)cur * (prev + cur + next);
-        prev = cur;
-        cur = next;
-        if (acc >= target || c == PC_NLAYERS - 1) {
-            if (WRITE) {
-                work[PC_G_SEGS + 2 * (slot + segs)] = pencil + 1;
-                work[PC_G_SEGS + 2 * (slot + segs) + 1] = (uint32_t)z_begin | ((uint32_t)(c + 1) << 16);
-            }
-            segs++;
-            z_begin = c + 1;
-            acc = 0;
-        }
-    }
-    return segs;
-}
+// Planning: a workgroup of 16 waves per 64 home pencils of the slab, four pencils
+// per wave.  A pencil with many points is cut wherever the running cost estimate
+// passes a multiple of PC_G_PLAN_TARGET (the cost of one cell is capped at the
+// target, so the running sum of a pencil fits 32 bits); its segments are appended to
+// the list (all of them or, if the list is full, none) and its flag tells the pair
+// test to leave the pencil to the segment phase.  The segments of a pencil always
+// cover the cells [0, 400) exactly.  Lane l looks at the cells l, l + 64, ... so the
+// table row is read in whole lines; the workgroup reserves the list slots of its 64
+// pencils with one atomic (the counter is a single address: one atomic per pencil
+// would serialise the whole kernel on it).
+#define PC_G_PLAN_STEPS ((PC_NLAYERS + 63) / 64)
+#define PC_G_PLAN_PENCILS 64             // per workgroup
+#define PC_G_PLAN_TPB 1024
+static_assert((unsigned long long)PC_G_PLAN_TARGET * PC_NLAYERS < 0xFFFFFFFFull, "running cost of a pencil must fit 32 bits");
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(PC_G_PLAN_TPB)
 pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__restrict__ work, uint32_t seg_cap,
            uint32_t full_pencil)    // a pencil with more points than this counts as dense (several times the average)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= (x_hi - x_lo) * PC_NLAYERS) return;
-    const int layer = x_lo + t / PC_NLAYERS, j = t % PC_NLAYERS;
-    const uint32_t pencil = (uint32_t)layer * PC_NBB + j;
-    const uint32_t *row = T + (uint64_t)pencil * PC_NBB;
-    unsigned char planned = 0;
-    const uint32_t population = row[PC_NLAYERS] - row[0];
-    if (population > full_pencil) atomicAdd(work + PC_G_DENSE_POINTS, population);
-    if (population >= PC_G_PLAN_MIN_POINTS) {
-        const unsigned long long target = PC_G_PLAN_TARGET;
-        const uint32_t segs = pc_plan_walk<false>(row, pencil, work, 0, target);
-        if (segs >= 2) {
-            const uint32_t at = atomicAdd(work + PC_G_SEG_COUNT, segs);
-            if (at + segs <= seg_cap) {
-                pc_plan_walk<true>(row, pencil, work, at, target);
-                planned = 1;
-            } else {
-                // the list is full: the pencil stays whole, the slots it reserved below the cap stay empty
-                for (uint32_t q = at; q < seg_cap; q++) work[PC_G_SEGS + 2 * q] = 0;
+    __shared__ unsigned long long ends[PC_G_PLAN_PENCILS][PC_G_PLAN_STEPS];   // per 64 cells: the cells that close a segment
+    __shared__ uint32_t seg_n[PC_G_PLAN_PENCILS], seg_at[PC_G_PLAN_PENCILS];
+    __shared__ unsigned long long to_plan;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_pencils = (x_hi - x_lo) * PC_NLAYERS, per_wave = PC_G_PLAN_PENCILS / (PC_G_PLAN_TPB / 64);
+    const uint32_t target = PC_G_PLAN_TARGET;
+    // the populations first, a thread per pencil: on most inputs no pencil of the workgroup needs a plan
+    if (wave == 0) {
+        const int t = blockIdx.x * PC_G_PLAN_PENCILS + lane;
+        uint32_t population = 0;
+        if (t < n_pencils) {
+            const uint32_t *row = T + (uint64_t)((uint32_t)(x_lo + t / PC_NLAYERS) * PC_NBB + t % PC_NLAYERS) * PC_NBB;
+            population = row[PC_NLAYERS] - row[0];
+        }
+        const uint32_t dense_total = pc_wave_sum(population > full_pencil ? population : 0);
+        if (lane == 0 && dense_total) atomicAdd(work + PC_G_DENSE_POINTS, dense_total);
+        const unsigned long long need = __builtin_amdgcn_ballot_w64(population >= PC_G_PLAN_MIN_POINTS);
+        if (lane == 0) to_plan = need;
+        if (!need && t < n_pencils)
+            reinterpret_cast<unsigned char *>(work + PC_G_FLAGS)[(uint32_t)(x_lo + t / PC_NLAYERS) * PC_NBB + t % PC_NLAYERS] = 0;
+    }
+    __syncthreads();
+    const unsigned long long need = to_plan;
+    if (!need) return;
+    for (int q = 0; q < per_wave; q++) {
+        const int slot = wave * per_wave + q, t = blockIdx.x * PC_G_PLAN_PENCILS + slot;
+        uint32_t segs = 0;
+        if (t < n_pencils) {
+            const uint32_t *row = T + (uint64_t)((uint32_t)(x_lo + t / PC_NLAYERS) * PC_NBB + t % PC_NLAYERS) * PC_NBB;
+            if ((need >> slot) & 1) {
+                uint32_t running = 0;
+#pragma unroll
+                for (int u = 0; u < PC_G_PLAN_STEPS; u++) {
+                    const int c = u * 64 + lane;
+                    uint32_t cost = 0;
+                    if (c < PC_NLAYERS) {
+                        const uint32_t r0 = row[c > 0 ? c - 1 : 0], r1 = row[c], r2 = row[c + 1], r3 = row[c + 2];
+                        const unsigned long long full = (unsigned long long)(r2 - r1) * ((r1 - r0) + (r2 - r1) + (r3 - r2));
+                        cost = full < target ? (uint32_t)full : target;
+                    }
+                    const uint32_t incl = pc_wave_incl_scan(cost) + running;
+                    const bool end = c < PC_NLAYERS && (incl / target != (incl - cost) / target || c == PC_NLAYERS - 1);
+                    const unsigned long long e = __builtin_amdgcn_ballot_w64(end);
+                    if (lane == 0) ends[slot][u] = e;
+                    segs += (uint32_t)__popcll(e);
+                    running = __builtin_amdgcn_readlane(incl, 63);
+                }
             }
         }
+        if (lane == 0) seg_n[slot] = segs >= 2 ? segs : 0;       // a pencil of one segment stays whole
     }
-    reinterpret_cast<unsigned char *>(work + PC_G_FLAGS)[pencil] = planned;
+    __syncthreads();
+    if (wave == 0) {
+        // one reservation for the workgroup's pencils, in pencil order
+        const uint32_t mine = seg_n[lane];
+        const uint32_t incl = pc_wave_incl_scan(mine);
+        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+        uint32_t base = 0;
+        if (lane == 0 && total) base = atomicAdd(work + PC_G_SEG_COUNT, total);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const uint32_t at = base + incl - mine;
+        seg_at[lane] = at;
+        const int t = blockIdx.x * PC_G_PLAN_PENCILS + lane;
+        if (t < n_pencils)
+            reinterpret_cast<unsigned char *>(work + PC_G_FLAGS)[(uint32_t)(x_lo + t / PC_NLAYERS) * PC_NBB + t % PC_NLAYERS] =
+                mine && at + mine <= seg_cap;
+    }
+    __syncthreads();
+    for (int q = 0; q < per_wave; q++) {
+        const int slot = wave * per_wave + q, t = blockIdx.x * PC_G_PLAN_PENCILS + slot;
+        const uint32_t segs = seg_n[slot];
+        uint32_t at = seg_at[slot];
+        if (!segs) continue;
+        if (at + segs <= seg_cap) {
+            const uint32_t pencil = (uint32_t)(x_lo + t / PC_NLAYERS) * PC_NBB + t % PC_NLAYERS;
+            int z_after = 0;                               // first cell after the last segment closed in earlier steps
+#pragma unroll
+            for (int u = 0; u < PC_G_PLAN_STEPS; u++) {
+                const unsigned long long e = ends[slot][u], below = e & ((1ull << lane) - 1);
+                if ((e >> lane) & 1) {
+                    const int z_begin = below ? u * 64 + 64 - __clzll(below) : z_after;
+                    const uint32_t w = at + (uint32_t)__popcll(below);
+                    work[PC_G_SEGS + 2 * w] = pencil + 1;
+                    work[PC_G_SEGS + 2 * w + 1] = (uint32_t)z_begin | ((uint32_t)(u * 64 + lane + 1) << 16);
+                }
+                at += (uint32_t)__popcll(e);
+                if (e) z_after = u * 64 + 64 - __clzll(e);
+            }
+        } else {
+            // the list is full: the pencil stays whole, the slots it reserved below the cap stay empty
+            for (uint32_t w = at + lane; w < seg_cap; w += 64) work[PC_G_SEGS + 2 * w] = 0;
+        }
+    }
 }
 
 // WHOLE_PENCILS false: the whole pencils have been counted by another kernel, only the listed segments are left
