@@ -336,7 +336,7 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
     PC_LAUNCH("pc_l2_scan_x", pc_l2_scan_x, dim3(1), dim3(512), s, w.layer_count, w.layer_start, w.layer_cursor,
               w.layer_tile, w.tile_layer);
     if (n) {
-        PC_LAUNCH("pc_l3_partition_x", pc_l36_partition<0>, dim3(tiles), dim3(PC_L_PTPB), s, d_xyz, n, d_sorted,
+        PC_LAUNCH("pc_l3_partition_x", pc_l36_partition<0>, dim3(tiles), dim3(PC_L_XTPB), s, d_xyz, n, d_sorted,
                   w.layer_start, w.layer_tile, w.tile_layer, w.layer_cursor, w.ycell, t_geo);
         PC_LAUNCH("pc_l4_hist_y", pc_l4_hist_y, dim3(tiles + PC_NBB), dim3(PC_L_TPB), s, w.ycell, w.layer_start,
                   w.layer_tile, w.tile_layer, w.pencil_count, d_status, t_geo);

@@ -10,7 +10,7 @@
 // variant 0's per-point global atomics: every histogram and every slot claim is an
 // LDS atomic; global atomics are one per (tile, non-empty bin).  Each partition
 // pass sorts a tile of points by bin inside LDS and then writes every bin's run
-// with coalesced dword stores, so all three passes stream at HBM rate.
+// with 12-byte stores from consecutive lanes, so all three passes stream at HBM rate.
 //
 // L3 also records every point's y cell (2 bytes, in level-X order), so the level-Y
 // histogram reads 2 bytes per point instead of the point itself.
@@ -26,7 +26,12 @@
 #define PC_L_PPT 16
 #endif
 #define PC_L_TILE (PC_L_TPB * PC_L_PPT)        // 4096 points = 48 KB of LDS
-#define PC_L_PTPB 512                          // partition kernels: threads per tile
+#ifndef PC_L_PTPB
+#define PC_L_PTPB 512                          // partition kernels: threads per tile (level Y and the huge pencils) ...
+#endif
+#ifndef PC_L_XTPB
+#define PC_L_XTPB 1024                         // ... and in level X (measured: 0.55 ms against 0.58 with 512; level Y 0.48 against 0.50 the other way)
+#endif
 #define PC_L_PPPT (PC_L_TILE / PC_L_PTPB)      // and points per thread
 #define PC_L_NPENCILS (PC_NBB * PC_NBB)        // 162409, padding pencils included
 #define PC_L_BINS 404
@@ -239,14 +244,14 @@ pc_l5_scan_y(const uint32_t *__restrict__ pencil_count, const uint32_t *__restri
 // LEVEL 1: tile = a chunk of one layer, bin = y cell,
 //          cursors = that layer's row of pencil_cursor.
 template <int LEVEL>
-__global__ void __launch_bounds__(PC_L_PTPB)
+__global__ void __launch_bounds__(LEVEL == 0 ? PC_L_XTPB : PC_L_PTPB)
 pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ dst,
                  const uint32_t *__restrict__ layer_start, const uint32_t *__restrict__ layer_tile,
                  const uint32_t *__restrict__ tile_layer, uint32_t *__restrict__ cursor, uint16_t *__restrict__ ycell, const pc_geom geo)
 {
-    __shared__ float buf[PC_L_TILE * 3];              // the tile sorted by bin
-    __shared__ uint16_t bin_of[PC_L_TILE];
-    __shared__ uint16_t ycell_of[LEVEL == 0 ? PC_L_TILE : 1];
+    constexpr int TPB = LEVEL == 0 ? PC_L_XTPB : PC_L_PTPB, PPT = PC_L_TILE / TPB;
+    __shared__ float buf[PC_L_TILE * 3];              // the tile sorted by bin: 48 KB, with the three small arrays 54 000 bytes,
+                                                      // so that three workgroups share a CU's 160 KB
     __shared__ uint32_t hist[PC_L_BINS];
     __shared__ uint32_t lstart[PC_L_BINS];
     __shared__ uint32_t delta[PC_L_BINS];             // global slot of bin's first point minus lstart
@@ -267,26 +272,21 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
         cnt = min((uint32_t)PC_L_TILE, layer_start[layer + 1] - (uint32_t)first);
         cursor += (blockIdx.x % PC_L_NREP) * PC_L_PSTRIDE + layer * PC_NBB;
     }
-    for (int b = tid; b < PC_L_BINS; b += PC_L_PTPB) hist[b] = 0;
+    for (int b = tid; b < PC_L_BINS; b += TPB) hist[b] = 0;
     // the tile -> registers: thread t takes points t, t+TPB, ... (12-byte loads,
     // consecutive lanes on consecutive points); all loads are issued before any use
     const pc_pt3 *g = reinterpret_cast<const pc_pt3 *>(src) + first;
-    pc_pt3 pt[PC_L_PPPT];
-    uint32_t yc[PC_L_PPPT];
+    pc_pt3 pt[PPT];
 #pragma unroll
-    for (int j = 0; j < PC_L_PPPT; j++) pt[j] = g[min((uint32_t)(tid + j * PC_L_PTPB), cnt - 1)];
+    for (int j = 0; j < PPT; j++) pt[j] = g[min((uint32_t)(tid + j * TPB), cnt - 1)];
     __syncthreads();
 
     // bin and rank inside the bin (LDS atomic) of each point
-    uint32_t tag[PC_L_PPPT];                           // bin | rank << 10, or ~0 for "skip"
+    uint32_t tag[PPT];                           // bin | rank << 10, or ~0 for "skip"
 #pragma unroll
-    for (int j = 0; j < PC_L_PPPT; j++) {
+    for (int j = 0; j < PPT; j++) {
         tag[j] = 0xFFFFFFFFu;
-        if ((uint32_t)(tid + j * PC_L_PTPB) < cnt) {
-            if (LEVEL == 0) {
-                const int cy = pc_cell_index(pt[j].y, geo);
-                yc[j] = (unsigned)cy < (unsigned)geo.ncell ? (uint32_t)cy : 0xFFFFu;
-            }
+        if ((uint32_t)(tid + j * TPB) < cnt) {
             const uint32_t b = (uint32_t)pc_cell_index(LEVEL == 0 ? pt[j].x : pt[j].y, geo);
             if (b < (unsigned)geo.ncell) tag[j] = b | (atomicAdd(&hist[b], 1u) << 10);
         }
@@ -312,32 +312,34 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
     }
     __syncthreads();
     // claim global space: one atomic per non-empty bin
-    for (int b = tid; b < PC_L_BINS; b += PC_L_PTPB) {
+    for (int b = tid; b < PC_L_BINS; b += TPB) {
         const uint32_t c = hist[b];
         if (c) delta[b] = atomicAdd(&cursor[b], c) - lstart[b];
     }
     // the tile in bin order -> LDS
 #pragma unroll
-    for (int j = 0; j < PC_L_PPPT; j++) {
+    for (int j = 0; j < PPT; j++) {
         if (tag[j] != 0xFFFFFFFFu) {
             const uint32_t b = tag[j] & 1023u, pos = lstart[b] + (tag[j] >> 10);
             buf[3 * pos] = pt[j].x;
             buf[3 * pos + 1] = pt[j].y;
             buf[3 * pos + 2] = pt[j].z;
-            bin_of[pos] = (uint16_t)b;
-            if (LEVEL == 0) ycell_of[pos] = (uint16_t)yc[j];
         }
     }
     __syncthreads();
-    // runs -> global, coalesced dwords
     const uint32_t kept = lstart[PC_L_BINS - 1] + hist[PC_L_BINS - 1];
-    for (uint32_t d = tid; d < 3 * kept; d += PC_L_PTPB) {
-        const uint32_t e = d / 3u;
-        const uint32_t slot = delta[bin_of[e]] + e;
-        dst[3 * (uint64_t)slot + (d - 3u * e)] = buf[d];
+    // runs -> global, a point per lane (12-byte stores, consecutive lanes on consecutive slots of a run); the bin
+    // is computed again from the coordinate, which leaves the LDS to the points alone
+    for (uint32_t e = tid; e < kept; e += TPB) {
+        const pc_pt3 p = {buf[3 * e], buf[3 * e + 1], buf[3 * e + 2]};
+        const uint32_t b = (uint32_t)pc_cell_index(LEVEL == 0 ? p.x : p.y, geo);
+        const uint32_t slot = delta[b] + e;
+        reinterpret_cast<pc_pt3 *>(dst)[slot] = p;
+        if (LEVEL == 0) {
+            const int cy = pc_cell_index(p.y, geo);
+            ycell[slot] = (unsigned)cy < (unsigned)geo.ncell ? (uint16_t)cy : (uint16_t)0xFFFFu;
+        }
     }
-    if (LEVEL == 0)
-        for (uint32_t e = tid; e < kept; e += PC_L_PTPB) ycell[delta[bin_of[e]] + e] = ycell_of[e];
 }
 
 // ---- L7: one wave sorts one pencil by z cell and writes its table slice --------
