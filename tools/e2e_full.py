@@ -19,12 +19,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def timed(cmd, env=None):
+def timed(cmd, env=None, runs=2, limit=None):
+    """Best wall time of `runs` runs; None if a run exceeds `limit` seconds."""
     best = None
-    for _ in range(2):
+    for _ in range(runs):
         t = time.time()
-        r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        while True:                      # (a line a minute while a long run is under way)
+            try:
+                so, se = p.communicate(timeout=60)
+                break
+            except subprocess.TimeoutExpired:
+                print("  %s: running for %d s" % (os.path.basename(cmd[0]), time.time() - t), flush=True)
+                if limit and time.time() - t > limit:
+                    p.kill()
+                    p.communicate()
+                    print("  %s: no result within %d s" % (os.path.basename(cmd[0]), limit), flush=True)
+                    return None
         w = time.time() - t
+        r = subprocess.CompletedProcess(cmd, p.returncode, so, se)
         if r.returncode != 0:
             raise SystemExit("%s failed: %s" % (cmd[0], r.stderr[-300:]))
         if best is None or w < best[0]:
@@ -37,6 +50,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="uniform100m")
     ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--points", type=int, default=None, help="another number of points than the workload's")
+    ap.add_argument("--reference-runs", type=int, default=2)
+    ap.add_argument("--reference-limit", type=int, default=None, help="give the reference up after this many seconds")
     ap.add_argument("--skip-reference", action="store_true", help="time only the product's host program")
     ap.add_argument("--gpu-tokenizer", type=int, nargs="*", default=[],
                     help="also time the host program with PAIRCOUNT_GPU_TOKENIZER=K for each K given (K threads at a time "
@@ -51,6 +67,8 @@ def main():
     ht = importlib.import_module("particle_simulation_amd.hosttools")
     kind_name, points, sigma, _ = bench.WORKLOADS[args.workload]
     kind = ht.UNIFORM if kind_name == "uniform" else ht.BLOBS
+    if args.points:
+        points = args.points
     tmp = tempfile.mkdtemp(prefix="pce2e_")
     path = os.path.join(tmp, "input.xyz")
     t = time.time()
@@ -70,10 +88,15 @@ def main():
                 "phases_s": {m.group(1): float(m.group(2)) / 1e6 for m in re.finditer(r"(\w[\w()]*):\s+(\d+) us", r.stderr)}}
         ref = os.path.join(ROOT, "oracle", "_ref", "main_timer")
         if os.path.exists(ref) and not args.skip_reference:
-            w, r = timed([ref, "-f", path, "-p", str(args.threads), "-c", str(args.threads)])
-            out["reference"] = {"wall_s": w, "count": int([ln for ln in r.stdout.splitlines() if ln.strip().isdigit()][-1]),
-                                "phases_s": {m.group(1): int(m.group(2)) / 1e6 for m in re.finditer(r"(\w+):\s+(\d+) us", r.stdout)}}
-            out["counts_equal"] = out["reference"]["count"] == out["gpu_host_program"]["count"]
+            got = timed([ref, "-f", path, "-p", str(args.threads), "-c", str(args.threads)], runs=args.reference_runs,
+                        limit=args.reference_limit)
+            if got is None:
+                out["reference"] = {"wall_s": None, "note": "no result within %d s" % args.reference_limit}
+            else:
+                w, r = got
+                out["reference"] = {"wall_s": w, "count": int([ln for ln in r.stdout.splitlines() if ln.strip().isdigit()][-1]),
+                                    "phases_s": {m.group(1): int(m.group(2)) / 1e6 for m in re.finditer(r"(\w+):\s+(\d+) us", r.stdout)}}
+                out["counts_equal"] = out["reference"]["count"] == out["gpu_host_program"]["count"]
         if args.sidecar:
             side = os.path.join(tmp, "input.f32")
             ht.generate(kind, 7, points, sigma).tofile(side)
