@@ -17,11 +17,26 @@
 #include <string.h>
 
 #include "xyz_parse.h"
+#include "xyz_route.h"
 
 #define XYZ_MAX_THREADS 256
 
 /* ---- cell routing (host copy of the key formula, reference main.c:134) ---- */
 int xyz_cell_index(float f) { return (int)(((double)f + 10.0) / 0.05); }
+
+/* Number of binary32 bit patterns in [first, first + count) for which the routing shortcut
+   (xyz_route.h) and the reference's expression name different layers. */
+uint64_t xyz_selfcheck_route_layers(uint64_t first, uint64_t count)
+{
+    uint64_t bad = 0;
+    for (uint64_t b = first; b < first + count; b++) {
+        const uint32_t bits = (uint32_t)b;
+        float f;
+        memcpy(&f, &bits, 4);
+        bad += xyz_route_layer(f) != xyz_route_layer_exact(f);
+    }
+    return bad;
+}
 
 /* ---- tokenizer exports (tests bind these) --------------------------------- */
 uint32_t xyz_token_bits(const char *tok, int *consumed, int *err)

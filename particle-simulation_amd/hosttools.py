@@ -28,6 +28,8 @@ def lib():
         L.xyz_selfcheck_fast_tokens.argtypes = []
         L.xyz_selfcheck_line_fuzz.restype = c.c_uint64
         L.xyz_selfcheck_line_fuzz.argtypes = [c.c_uint64, c.c_uint64]
+        L.xyz_selfcheck_route_layers.restype = c.c_uint64
+        L.xyz_selfcheck_route_layers.argtypes = [c.c_uint64, c.c_uint64]
         L.xyz_parse_buffer_mt.restype = c.c_int64
         L.xyz_parse_buffer_mt.argtypes = [c.c_char_p, c.c_uint64, c.c_int, c.c_void_p, c.c_uint64]
         L.xyz_gen_f32.restype = c.c_int64
@@ -70,6 +72,17 @@ def selfcheck_fast_tokens():
 def selfcheck_line_fuzz(seed, lines):
     """Disagreements between the bounded (short-cut) and the general line parser on random, partly damaged lines."""
     return int(lib().xyz_selfcheck_line_fuzz(int(seed), int(lines)))
+
+
+def selfcheck_route_layers(first=0, count=1 << 32, threads=None):
+    """Bit patterns in [first, first + count) whose x layer the host program's routing short cut (binary32)
+    names differently from the reference's binary64 expression; 0 is the only acceptable answer."""
+    from concurrent.futures import ThreadPoolExecutor
+    threads = threads or host_threads()
+    step = (count + threads - 1) // threads
+    parts = [(first + i * step, min(step, count - i * step)) for i in range(threads) if i * step < count]
+    with ThreadPoolExecutor(len(parts)) as pool:                   # (ctypes calls release the interpreter lock)
+        return sum(pool.map(lambda fc: int(lib().xyz_selfcheck_route_layers(fc[0], fc[1])), parts))
 
 
 def parse_text(data, threads=4):

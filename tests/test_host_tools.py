@@ -158,3 +158,10 @@ def test_layer_cost_matches_a_numpy_restatement(psa):
     want = 13.5 * (blocks ** 2).sum(axis=(1, 2)) / 64.0 + 40.0 * blocks.sum(axis=(1, 2))
     got = ht.layer_cost(ht.BLOBS, 5, n, sigma, per_point=40.0, threads=3)
     assert np.allclose(got, want, rtol=1e-12, atol=1e-9)
+
+
+def test_routing_short_cut_names_the_reference_layer_for_every_float(ht):
+    """The multi-GPU host program routes a point to the slab that owns its x layer; the layer comes from a
+    binary32 short cut of the reference's cell formula (main.c:134) with the formula itself near cell
+    boundaries.  All 2^32 bit patterns, NaNs and infinities included."""
+    assert ht.selfcheck_route_layers() == 0

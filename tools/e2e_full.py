@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--gpu-tokenizer", type=int, nargs="*", default=[],
                     help="also time the host program with PAIRCOUNT_GPU_TOKENIZER=K for each K given (K threads at a time "
                          "send their block of text through the GPU tokenizer, the others tokenize on the host)")
+    ap.add_argument("--slabs", type=int, nargs="*", default=[],
+                    help="also time the host program with -g S for each S given, all S slabs on device 0 "
+                         "(the multi-GPU path of the host program on a one-GPU box)")
     ap.add_argument("--sidecar", action="store_true",
                     help="also time the host program on the .f32 form of the same points (no tokenizing)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "e2e_full.json"))
@@ -86,6 +89,13 @@ def main():
             out["gpu_host_program_gpu_tokenizer_%d" % k] = {
                 "wall_s": w, "count": int(r.stdout.strip()),
                 "phases_s": {m.group(1): float(m.group(2)) / 1e6 for m in re.finditer(r"(\w[\w()]*):\s+(\d+) us", r.stderr)}}
+        for k in args.slabs:
+            w, r = timed([ht.MAIN_PATH, "-f", path, "-p", str(args.threads), "-g", str(k)],
+                         env=dict(os.environ, PAIRCOUNT_TIMER="1", PAIRCOUNT_DEVICES=",".join(["0"] * k)))
+            out["gpu_host_program_%d_slabs_on_one_gpu" % k] = {
+                "wall_s": w, "count": int(r.stdout.strip()),
+                "phases_s": {m.group(1): float(m.group(2)) / 1e6 for m in re.finditer(r"(\w[\w()]*):\s+(\d+) us", r.stderr)},
+                "slabs": [ln.strip() for ln in r.stderr.splitlines() if ln.strip().startswith("slab")]}
         ref = os.path.join(ROOT, "oracle", "_ref", "main_timer")
         if os.path.exists(ref) and not args.skip_reference:
             got = timed([ref, "-f", path, "-p", str(args.threads), "-c", str(args.threads)], runs=args.reference_runs,
