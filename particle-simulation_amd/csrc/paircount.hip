@@ -1251,3 +1251,21 @@ extern "C" void pc_destroy(pc_context *c)
     pthread_mutex_destroy(&c->reserve);
     free(c);
 }
+
+#ifdef PC_L_TRACE
+// Measurement build only: reads and clears the partition kernels' phase counters (see pc_bin_lds.h).
+extern "C" int pc_trace_read(unsigned long long out[16])
+{
+    static unsigned long long rows[2][PC_L_TRACE_ROWS][8];
+    PC_HIP(hipDeviceSynchronize());
+    PC_HIP(hipMemcpyFromSymbol(rows, HIP_SYMBOL(pc_l_trace), sizeof rows));
+    for (int l = 0; l < 2; l++)
+        for (int i = 0; i < 8; i++) {
+            out[8 * l + i] = 0;
+            for (int r = 0; r < PC_L_TRACE_ROWS; r++) out[8 * l + i] += rows[l][r][i];
+        }
+    memset(rows, 0, sizeof rows);
+    PC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pc_l_trace), rows, sizeof rows));
+    return PC_OK;
+}
+#endif

@@ -238,6 +238,24 @@ pc_l5_scan_y(const uint32_t *__restrict__ pencil_count, const uint32_t *__restri
     if (layer == PC_NBB - 1 && j == PC_NBB) pencil_start[PC_L_NPENCILS] = ex;   // total
 }
 
+#ifdef PC_L_TRACE
+// Measurement build only: shader-clock cycles that the workgroups of the partition kernels spend in each phase,
+// kept in registers by thread 0 and added at the workgroup's end to one of 64 rows (atomics on a single address
+// would serialise the kernel); [level][row][phase], phase 7 = workgroups counted.  Read with pc_trace_read.
+#define PC_L_TRACE_ROWS 64
+__device__ unsigned long long pc_l_trace[2][PC_L_TRACE_ROWS][8];
+#define PC_L_MARK(i)                                                                         \
+    do {                                                                                     \
+        if (tid == 0) {                                                                      \
+            const unsigned long long now_ = __builtin_readcyclecounter();                   \
+            spent_[i] = now_ - mark_;                                                        \
+            mark_ = now_;                                                                    \
+        }                                                                                    \
+    } while (0)
+#else
+#define PC_L_MARK(i) do { } while (0)
+#endif
+
 // ---- L3 / L6: partition a tile of points into 403 bins -----------------------
 // LEVEL 0: tile = points [blockIdx*TILE, +TILE) of the input, bin = x cell,
 //          cursors = layer_cursor; writes ycell[] beside the points.
@@ -272,6 +290,9 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
         cnt = min((uint32_t)PC_L_TILE, layer_start[layer + 1] - (uint32_t)first);
         cursor += (blockIdx.x % PC_L_NREP) * PC_L_PSTRIDE + layer * PC_NBB;
     }
+#ifdef PC_L_TRACE
+    unsigned long long mark_ = __builtin_readcyclecounter(), spent_[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int b = tid; b < PC_L_BINS; b += TPB) hist[b] = 0;
     // the tile -> registers: thread t takes points t, t+TPB, ... (12-byte loads,
     // consecutive lanes on consecutive points); all loads are issued before any use
@@ -279,7 +300,11 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
     pc_pt3 pt[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; j++) pt[j] = g[min((uint32_t)(tid + j * TPB), cnt - 1)];
+#ifdef PC_L_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     __syncthreads();
+    PC_L_MARK(0);                                      // the tile has arrived
 
     // bin and rank inside the bin (LDS atomic) of each point
     uint32_t tag[PPT];                           // bin | rank << 10, or ~0 for "skip"
@@ -292,6 +317,7 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
         }
     }
     __syncthreads();
+    PC_L_MARK(1);                                      // ranked
 
     // exclusive scan of the 404 bins by wave 0 (7 bins per lane)
     if (tid < 64) {
@@ -311,10 +337,16 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
         }
     }
     __syncthreads();
-    // claim global space: one atomic per non-empty bin
-    for (int b = tid; b < PC_L_BINS; b += TPB) {
-        const uint32_t c = hist[b];
-        if (c) delta[b] = atomicAdd(&cursor[b], c) - lstart[b];
+    PC_L_MARK(2);                                      // scanned
+    // claim global space: one atomic per non-empty bin; its answer is awaited only after the tile has been
+    // copied into LDS (the claims take about as long as that copy)
+    constexpr int CLAIMS = (PC_L_BINS + TPB - 1) / TPB;
+    uint32_t claimed[CLAIMS];
+#pragma unroll
+    for (int q = 0; q < CLAIMS; q++) {
+        const int b = tid + q * TPB;
+        claimed[q] = 0;
+        if (b < PC_L_BINS && hist[b]) claimed[q] = atomicAdd(&cursor[b], hist[b]);
     }
     // the tile in bin order -> LDS
 #pragma unroll
@@ -326,7 +358,17 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
             buf[3 * pos + 2] = pt[j].z;
         }
     }
+#pragma unroll
+    for (int q = 0; q < CLAIMS; q++) {
+        const int b = tid + q * TPB;
+        if (b < PC_L_BINS) delta[b] = claimed[q] - lstart[b];
+    }
+#ifdef PC_L_TRACE
+    PC_L_MARK(3);                                      // tile scattered into LDS (this thread's share), claims issued
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
     __syncthreads();
+    PC_L_MARK(4);                                      // claims answered, LDS complete
     const uint32_t kept = lstart[PC_L_BINS - 1] + hist[PC_L_BINS - 1];
     // runs -> global, a point per lane (12-byte stores, consecutive lanes on consecutive slots of a run); the bin
     // is computed again from the coordinate, which leaves the LDS to the points alone
@@ -340,6 +382,16 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
             ycell[slot] = (unsigned)cy < (unsigned)geo.ncell ? (uint16_t)cy : (uint16_t)0xFFFFu;
         }
     }
+#ifdef PC_L_TRACE
+    PC_L_MARK(5);                                      // stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PC_L_MARK(6);                                      // stores acknowledged
+    if (tid == 0) {
+        unsigned long long *row = pc_l_trace[LEVEL][blockIdx.x % PC_L_TRACE_ROWS];
+        for (int i = 0; i < 7; i++) atomicAdd(&row[i], spent_[i]);
+        atomicAdd(&row[7], 1ull);
+    }
+#endif
 }
 
 // ---- L7: one wave sorts one pencil by z cell and writes its table slice --------
