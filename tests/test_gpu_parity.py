@@ -29,10 +29,12 @@ def default_variants(psa):
     psa.set_variant("bin", 1)
     psa.set_variant("count", 4)
     psa.set_variant("dense", 1)
+    psa.set_variant("even", 1)
     yield
     psa.set_variant("bin", 1)
     psa.set_variant("count", 4)
     psa.set_variant("dense", 1)
+    psa.set_variant("even", 1)
 
 
 def dev(torch_mod, a):
