@@ -193,23 +193,30 @@ int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t *d_cell_sta
 int pc_count_tests_device(const uint32_t *d_cell_start, int x_lo, int x_hi,
                           uint64_t *d_ntests, void *stream);
 
-/* Whole hot path on device-resident input: keys, binning, pair test.
-   d_sorted_xyz / d_cell_start as above (outputs, kept for inspection), except
-   that they are complete only for the x layers x_lo .. x_hi (the slab and its
-   halo layer, all the pair test reads; with x_hi = 400 also the two empty
-   padding layers, i.e. to the end of the table); *d_npairs is overwritten with
-   the count. */
+/* Whole hot path on device-resident input: keys, binning, pair test;
+   *d_npairs is overwritten with the count.  d_sorted_xyz / d_cell_start (sized
+   as above) are WORK AREAS of this call: on moderately filled grids (about 2/3
+   of a point to 2 points per cell) the last binning level runs inside the pair
+   test's LDS and neither the z-sorted array nor the table is written at all; on
+   other inputs they hold pc_bin_device's results for the x layers x_lo .. x_hi
+   (the slab and its halo layer, all the pair test reads).  Which of the two
+   happened is decided on the device.  Callers that want the table call
+   pc_bin_device, or pc_set_variant("count", 5) first (windowed pair test on the
+   sorted array, the table always written). */
 int pc_count_pairs_device(const float *d_xyz, uint64_t n, int x_lo, int x_hi,
                           float *d_sorted_xyz, uint32_t *d_cell_start,
                           void *d_workspace, size_t workspace_bytes,
                           uint64_t *d_npairs, int32_t *d_status, void *stream);
 
-/* pc_cell_keys_device, pc_count_pairs_device and pc_selfcheck_cell_index_device with
+/* pc_cell_keys_device, pc_bin_device, pc_count_pairs_device and pc_selfcheck_cell_index_device with
    an explicit geometry (see pc_geometry); with pc_geometry_default() they are the
    calls above, bit for bit.  No counterpart in the reference (main.c:30-31,165
    are compile-time constants there). */
 int pc_cell_keys_geometry_device(const pc_geometry *g, const float *d_xyz, uint64_t n, uint32_t *d_keys,
                                  int32_t *d_status, void *stream);
+int pc_bin_geometry_device(const pc_geometry *g, const float *d_xyz, uint64_t n, float *d_sorted_xyz,
+                           uint32_t *d_cell_start, void *d_workspace, size_t workspace_bytes,
+                           int32_t *d_status, void *stream);
 int pc_count_pairs_geometry_device(const pc_geometry *g, const float *d_xyz, uint64_t n, int x_lo, int x_hi,
                                    float *d_sorted_xyz, uint32_t *d_cell_start,
                                    void *d_workspace, size_t workspace_bytes,
@@ -232,7 +239,9 @@ int pc_count_pairs_noalloc(const float *d_xyz, uint64_t n, int x_lo, int x_hi,
                            uint64_t *d_npairs, int32_t *d_status, void *stream);
 
 /* Selects kernel variants (for A/B measurement and cross-checks); values are
-   documented next to the kernels.  name: "bin" | "count", or "segments": the
+   documented next to the kernels.  name: "bin" (0, 1) | "count" (0-5, 7; 4 = the
+   default choice by density, 7 = level Z fused into the pair test wherever a
+   pencil neighbourhood fits its LDS), or "segments": the
    capacity of the pair test's list of heavy-pencil segments (default and
    maximum 262144; 0 = never cut a pencil), or "heavy": the capacity of its list
    of over-full cells' home-particle chunks (default and maximum 65536; 0 = such

@@ -60,6 +60,7 @@ ABI = [
     ("pc_set_geometry", _i32, [_vp, _vp]),
     ("pc_cell_keys_geometry_device", _i32, [_vp, _vp, _u64, _vp, _vp, _vp]),
     ("pc_count_pairs_geometry_device", _i32, [_vp, _vp, _u64, _i32, _i32, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    ("pc_bin_geometry_device", _i32, [_vp, _vp, _u64, _vp, _vp, _vp, _sz, _vp, _vp]),
     ("pc_selfcheck_cell_index_geometry_device", _i32, [_vp, _vp, _vp]),
     ("pc_set_variant", _i32, [_c.c_char_p, _i32]),
     ("pc_profile_enable", _i32, [_i32]),
@@ -235,6 +236,11 @@ class DeviceStages:
     Buffers are allocated once for `capacity` points and reused; no call here
     synchronises or allocates, so the sequence can be timed with events on the
     current torch stream.
+
+    count_pairs() may leave the sorted array and the table unwritten (the library
+    then ran its last binning level inside the pair test); `.sorted`, `.table`,
+    count_sorted() and count_tests() bin the same points again first when that
+    may have happened, so they always see pc_bin_device's results.
     """
 
     def __init__(self, capacity, device="cuda:0"):
@@ -245,14 +251,31 @@ class DeviceStages:
         n = max(self.capacity, 1)
         self.ws_bytes = lib().pc_workspace_bytes(n)
         with torch.cuda.device(self.device):
-            self.sorted = torch.empty((n, 3), dtype=torch.float32, device=self.device)
-            self.table = torch.empty(TABLE_LEN, dtype=torch.int32, device=self.device)
+            self._sorted = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+            self._table = torch.empty(TABLE_LEN, dtype=torch.int32, device=self.device)
             self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device)
             self.result = torch.zeros(2, dtype=torch.int64, device=self.device)   # [pairs, tests]
             self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
 
+        self._unbinned = None     # (xyz, geometry) of a count_pairs() whose table may not have been written
+
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def _binned(self):
+        if self._unbinned is not None:
+            xyz, geometry = self._unbinned
+            self.bin(xyz, geometry=geometry)
+
+    @property
+    def sorted(self):
+        self._binned()
+        return self._sorted
+
+    @property
+    def table(self):
+        self._binned()
+        return self._table
 
     def _n(self, xyz):
         t = self.torch
@@ -273,10 +296,16 @@ class DeviceStages:
                                                       self.status.data_ptr(), self._stream()))
         return keys[:n]
 
-    def bin(self, xyz):
+    def bin(self, xyz, geometry=None):
         n = self._n(xyz)
-        _check(lib().pc_bin_device(xyz.data_ptr(), n, self.sorted.data_ptr(), self.table.data_ptr(),
-                                   self.ws.data_ptr(), self.ws_bytes, self.status.data_ptr(), self._stream()))
+        self._unbinned = None
+        if geometry is None:
+            _check(lib().pc_bin_device(xyz.data_ptr(), n, self._sorted.data_ptr(), self._table.data_ptr(),
+                                       self.ws.data_ptr(), self.ws_bytes, self.status.data_ptr(), self._stream()))
+        else:
+            _check(lib().pc_bin_geometry_device(ctypes.byref(geometry), xyz.data_ptr(), n, self._sorted.data_ptr(),
+                                                self._table.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
+                                                self.status.data_ptr(), self._stream()))
         return n
 
     def count_sorted(self, n, x_lo=0, x_hi=PC_NLAYERS, zero=True):
@@ -295,14 +324,15 @@ class DeviceStages:
         """Whole hot path, asynchronous; the count lands in self.result[0]."""
         n = self._n(xyz)
         if geometry is None:
-            _check(lib().pc_count_pairs_device(xyz.data_ptr(), n, x_lo, x_hi, self.sorted.data_ptr(),
-                                               self.table.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
+            _check(lib().pc_count_pairs_device(xyz.data_ptr(), n, x_lo, x_hi, self._sorted.data_ptr(),
+                                               self._table.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
                                                self.result.data_ptr(), self.status.data_ptr(), self._stream()))
         else:
             _check(lib().pc_count_pairs_geometry_device(ctypes.byref(geometry), xyz.data_ptr(), n, x_lo, x_hi,
-                                                        self.sorted.data_ptr(), self.table.data_ptr(), self.ws.data_ptr(),
+                                                        self._sorted.data_ptr(), self._table.data_ptr(), self.ws.data_ptr(),
                                                         self.ws_bytes, self.result.data_ptr(), self.status.data_ptr(),
                                                         self._stream()))
+        self._unbinned = (xyz, geometry)
         return n
 
     def pairs(self):

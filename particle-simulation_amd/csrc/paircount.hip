@@ -19,6 +19,7 @@
 #include "pc_count_group.h"
 #include "pc_count_merge.h"
 #include "pc_count_dense.h"
+#include "pc_count_fused.h"
 #include "pc_generate.h"
 #include "pc_tokenize.h"
 
@@ -121,7 +122,9 @@ static int make_geom(const pc_geometry *in, pc_geom *out)
 static std::atomic<int> g_variant_bin{1};     // 0 = atomic counting sort, 1 = LDS-staged three-level bucket sort
 // 0 = global memory, 1 = LDS-tiled strips, 2 = wave per pencil, 3 = candidate-parallel groups,
 // 5 = merged single-run windows (variant 3's kernel for heavy pencils and what 5 defers),
-// 4 = by density: 0 below 2/3 of a point per cell of the slab on average, else 5
+// 7 = level Z fused into the pair test (whole-path entry points only; the z sort and variant 4's choice take
+//     over, decided on the device, when a pencil neighbourhood exceeds the fused kernel's capacity),
+// 4 = by density: 0 below 2/3 of a point per cell of the slab on average, 7 up to 1.9 (whole-path entry points), else 5
 static std::atomic<int> g_variant_count{4};
 static std::atomic<int> g_heavy{PC_G_HEAVY_CAP};    // capacity of the list of over-full cells' home-particle chunks (0: never listed)
 static std::atomic<int> g_segments{PC_G_SEG_CAP};  // capacity of the heavy-pencil segment list (0: pencils are never cut)
@@ -137,7 +140,7 @@ extern "C" int pc_set_variant(const char *name, int value)
         return PC_OK;
     }
     if (!strcmp(name, "count")) {
-        if (value < 0 || value > 5) return pc_fail(PC_ERR_ARG, "pc_set_variant: count variant %d unknown", value);
+        if (value < 0 || value > 7 || value == 6) return pc_fail(PC_ERR_ARG, "pc_set_variant: count variant %d unknown", value);
         g_variant_count = value;
         return PC_OK;
     }
@@ -329,10 +332,15 @@ static pc_lds_ws carve_lds_ws(void *ws, uint64_t n)
 
 // layers [layer_lo, layer_hi] get their pencils sorted and their table slices written (all: 0 .. PC_NBB-1)
 // (layer_counts: the [NREP][404] counts of L1 if they were taken while the points arrived, else null)
+// home layers [home_lo, home_hi) and `fused`: the call may be served by the fused pair test (level Z then runs
+// only if a pencil neighbourhood of the home layers exceeds that kernel's capacity: decided on the device)
 static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *table, void *ws,
-                   int32_t *d_status, hipStream_t s, int layer_lo, int layer_hi, const uint32_t *layer_counts = nullptr)
+                   int32_t *d_status, hipStream_t s, int layer_lo, int layer_hi, const uint32_t *layer_counts,
+                   int home_lo, int home_hi, bool fused)
 {
     pc_lds_ws w = carve_lds_ws(ws, n);
+    uint32_t *const gate_words = w.big_count + 2;                       // pc_fused_serves: [0] largest neighbourhood, [1] capacity
+    const uint32_t *const fgate = fused ? gate_words : nullptr;
     PC_HIP(hipMemsetAsync(w.layer_count, 0, (PC_L_NREP * PC_L_BINS + PC_L_NREP * PC_L_PSTRIDE + 8) * sizeof(uint32_t), s));
     const int tiles = (int)((n + PC_L_TILE - 1) / PC_L_TILE);
     if (layer_counts)
@@ -340,7 +348,7 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
     else if (n) PC_LAUNCH("pc_l1_hist_x", pc_l1_hist_x, dim3(grid_for(n, PC_L_TILE, 2048)), dim3(PC_L_TPB), s,
                           d_xyz, n, w.layer_count, d_status, t_geo);
     PC_LAUNCH("pc_l2_scan_x", pc_l2_scan_x, dim3(1), dim3(512), s, w.layer_count, w.layer_start, w.layer_cursor,
-              w.layer_tile, w.tile_layer);
+              w.layer_tile, w.tile_layer, gate_words + 1, (uint32_t)PC_F_CAP);
     if (n) {
         PC_LAUNCH("pc_l3_partition_x", pc_l36_partition<0>, dim3(tiles), dim3(PC_L_XTPB), s, d_xyz, n, d_sorted,
                   w.layer_start, w.layer_tile, w.tile_layer, w.layer_cursor, w.ycell, t_geo);
@@ -351,7 +359,8 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
     const uint64_t occupied_pencils = (uint64_t)(layer_hi < PC_NLAYERS ? layer_hi - layer_lo + 1 : PC_NLAYERS - layer_lo) * PC_NLAYERS;
     const bool sparse = n * 2 <= occupied_pencils * PC_L7_CAP_SPARSE;
     PC_LAUNCH("pc_l5_scan_y", pc_l5_scan_y, dim3(PC_NBB), dim3(512), s, w.pencil_count, w.layer_start,
-              w.pencil_start, w.pencil_cursor, (uint32_t)(sparse ? PC_L7_CAP_SPARSE : PC_L7_CAP), w.big_count, w.big_list);
+              w.pencil_start, w.pencil_cursor, (uint32_t)(sparse ? PC_L7_CAP_SPARSE : PC_L7_CAP), w.big_count, w.big_list,
+              home_lo, home_hi, gate_words);
     if (n)
         PC_LAUNCH("pc_l6_partition_y", pc_l36_partition<1>, dim3(tiles + PC_NBB), dim3(PC_L_PTPB), s, d_sorted, n,
                   w.tmp, w.layer_start, w.layer_tile, w.tile_layer, w.pencil_cursor, w.ycell, t_geo);
@@ -359,27 +368,27 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
     const dim3 l7_grid((end_pencil - first_pencil + PC_L7_WAVES - 1) / PC_L7_WAVES);
     if (sparse)
         PC_LAUNCH("pc_l7_sort_pencils", pc_l7_sort_pencils<PC_L7_CAP_SPARSE>, l7_grid, dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted,
-                  w.pencil_start, table, first_pencil, end_pencil, d_status, t_geo);
+                  w.pencil_start, table, first_pencil, end_pencil, d_status, t_geo, fgate);
     else
         PC_LAUNCH("pc_l7_sort_pencils", pc_l7_sort_pencils<PC_L7_CAP>, l7_grid, dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted,
-                  w.pencil_start, table, first_pencil, end_pencil, d_status, t_geo);
+                  w.pencil_start, table, first_pencil, end_pencil, d_status, t_geo, fgate);
     // pencils too big for a wave (listed by L5): one workgroup each, fixed grids walk the list, one per size class
     auto small = pc_l7b_sort_big_pencils<PC_L7B_CAP_SMALL, PC_L7B_TPB_SMALL>;
     auto large = pc_l7b_sort_big_pencils<PC_L7B_CAP_LARGE, PC_L7B_TPB_LARGE>;
     static int small_grid, large_grid;            // (one device model per process is assumed for these two)
     PC_LAUNCH("pc_l7b_sort_big_pencils", small, dim3(resident_blocks(small, PC_L7B_TPB_SMALL, &small_grid)), dim3(PC_L7B_TPB_SMALL), s, w.tmp, d_sorted, w.pencil_start, table,
               w.big_count, w.big_list, first_pencil, end_pencil, 0u, (uint32_t)PC_L7B_CAP_SMALL,
-              (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, d_status, t_geo);
+              (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, d_status, t_geo, fgate);
     PC_LAUNCH("pc_l7b_sort_bigger_pencils", large, dim3(resident_blocks(large, PC_L7B_TPB_LARGE, &large_grid)), dim3(PC_L7B_TPB_LARGE), s, w.tmp, d_sorted, w.pencil_start, table,
               w.big_count, w.big_list, first_pencil, end_pencil, (uint32_t)PC_L7B_CAP_SMALL, (uint32_t)PC_L7B_CAP_LARGE,
-              w.big_count + 1, w.huge_list, w.huge_count, d_status, t_geo);
+              w.big_count + 1, w.huge_list, w.huge_count, d_status, t_geo, fgate);
     // pencils beyond a workgroup's capacity (listed just now): tile-parallel histogram, scan, partition
     PC_LAUNCH("pc_l7h_hist", pc_l7h_hist, dim3(PC_L7H_GRID), dim3(PC_L_TPB), s, w.tmp, w.pencil_start, w.big_count + 1,
-              w.huge_list, w.huge_count, d_status, t_geo);
+              w.huge_list, w.huge_count, d_status, t_geo, fgate);
     PC_LAUNCH("pc_l7h_scan", pc_l7h_scan, dim3(256), dim3(64), s, w.pencil_start, w.big_count + 1, w.huge_list,
-              w.huge_count, w.huge_cursor, table);
+              w.huge_count, w.huge_cursor, table, fgate);
     PC_LAUNCH("pc_l7h_partition", pc_l7h_partition, dim3(PC_L7H_GRID), dim3(PC_L_PTPB), s, w.tmp, d_sorted, w.pencil_start,
-              w.big_count + 1, w.huge_list, w.huge_cursor, t_geo);
+              w.big_count + 1, w.huge_list, w.huge_cursor, t_geo, fgate);
     PC_HIP(hipGetLastError());
     return PC_OK;
 }
@@ -433,6 +442,17 @@ extern "C" int pc_cell_keys_geometry_device(const pc_geometry *g, const float *d
     return pc_cell_keys_device(d_xyz, n, d_keys, d_status, stream);
 }
 
+extern "C" int pc_bin_geometry_device(const pc_geometry *g, const float *d_xyz, uint64_t n, float *d_sorted_xyz,
+                                      uint32_t *d_cell_start, void *d_workspace, size_t workspace_bytes,
+                                      int32_t *d_status, void *stream)
+{
+    pc_geom geo;
+    int rc = make_geom(g, &geo);
+    if (rc) return rc;
+    geo_scope scope(geo);
+    return pc_bin_device(d_xyz, n, d_sorted_xyz, d_cell_start, d_workspace, workspace_bytes, d_status, stream);
+}
+
 extern "C" int pc_cell_keys_device(const float *d_xyz, uint64_t n, uint32_t *d_keys,
                                    int32_t *d_status, void *stream)
 {
@@ -448,7 +468,11 @@ extern "C" int pc_cell_keys_device(const float *d_xyz, uint64_t n, uint32_t *d_k
 
 static int bin_layers(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
                       uint32_t *d_cell_start, void *d_workspace, size_t workspace_bytes,
-                      int32_t *d_status, void *stream, int layer_lo, int layer_hi, const uint32_t *layer_counts = nullptr);
+                      int32_t *d_status, void *stream, int layer_lo, int layer_hi, const uint32_t *layer_counts = nullptr,
+                      int home_lo = 0, int home_hi = 0, bool fused = false);
+extern "C" int pc_bin_device(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
+                             uint32_t *d_cell_start, void *d_workspace, size_t workspace_bytes,
+                             int32_t *d_status, void *stream);
 
 extern "C" int pc_bin_device(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
                              uint32_t *d_cell_start, void *d_workspace, size_t workspace_bytes,
@@ -462,7 +486,8 @@ extern "C" int pc_bin_device(const float *d_xyz, uint64_t n, float *d_sorted_xyz
 // other layers; a slab's pair test never reads them).
 static int bin_layers(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
                       uint32_t *d_cell_start, void *d_workspace, size_t workspace_bytes,
-                      int32_t *d_status, void *stream, int layer_lo, int layer_hi, const uint32_t *layer_counts)
+                      int32_t *d_status, void *stream, int layer_lo, int layer_hi, const uint32_t *layer_counts,
+                      int home_lo, int home_hi, bool fused)
 {
     if (!d_cell_start || !d_status || !d_workspace)
         return pc_fail(PC_ERR_ARG, "pc_bin_device: null pointer");
@@ -472,7 +497,9 @@ static int bin_layers(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
         return pc_fail(PC_ERR_ARG, "pc_bin_device: workspace %zu < %zu bytes", workspace_bytes,
                        pc_workspace_bytes(n));
     hipStream_t s = (hipStream_t)stream;
-    if (g_variant_bin == 1) return bin_lds(d_xyz, n, d_sorted_xyz, d_cell_start, d_workspace, d_status, s, layer_lo, layer_hi, layer_counts);
+    if (g_variant_bin == 1)
+        return bin_lds(d_xyz, n, d_sorted_xyz, d_cell_start, d_workspace, d_status, s, layer_lo, layer_hi, layer_counts, home_lo,
+                       home_hi, fused);
     const uint64_t m = PC_NCELLS + 2;
     uint32_t *keys = (uint32_t *)d_workspace;
     uint32_t *sums = (uint32_t *)((char *)d_workspace + align_up((size_t)n * 4 + 4, 256));
@@ -529,9 +556,10 @@ static int check_slab(const char *who, int x_lo, int x_hi)
     return PC_OK;
 }
 
-extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t *d_cell_start,
-                                      uint64_t n, int x_lo, int x_hi, uint64_t *d_npairs,
-                                      void *stream)
+// fgate: the switch of a whole-path call that the fused pair test may serve (see pc_fused_serves), else null
+static int count_sorted(const float *d_sorted_xyz, const uint32_t *d_cell_start,
+                        uint64_t n, int x_lo, int x_hi, uint64_t *d_npairs,
+                        void *stream, const uint32_t *fgate)
 {
     if (!d_cell_start || !d_npairs) return pc_fail(PC_ERR_ARG, "pc_count_sorted_device: null pointer");
     if (!d_sorted_xyz && n) return pc_fail(PC_ERR_ARG, "pc_count_sorted_device: null point array");
@@ -540,6 +568,7 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
     if (rc) return rc;
     if (n == 0 || x_lo == x_hi) return PC_OK;
     int variant = g_variant_count;
+    if (variant == 7) variant = 4;                 // (the fused kernel is part of the whole-path entry points; this is their other route)
     if (variant == 4) {
         // Sparse inputs: a window of cells holds too few particles to pay for its bookkeeping, and the
         // thread-per-particle kernel wins (measured crossover at 42 M uniform points = 0.66 per cell).
@@ -550,7 +579,7 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
     if (variant == 0) {
         uint32_t c_lo = (uint32_t)x_lo * PC_NBB2, c_hi = (uint32_t)x_hi * PC_NBB2;
         PC_LAUNCH("pc_c0_count_global", pc_c0_count_global, dim3(grid_for(n, 256, 4096)), dim3(256), (hipStream_t)stream, d_sorted_xyz, d_cell_start, c_lo, c_hi,
-                           (unsigned long long *)d_npairs, t_geo);
+                           (unsigned long long *)d_npairs, t_geo, fgate);
     } else if (variant == 3 || variant == 5) {
         // persistent: one resident set of waves, never more waves than pencils;
         // the eight work counters are zeroed on the stream ahead of the launch
@@ -568,7 +597,7 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
         const uint32_t full_pencil = (uint32_t)(full < 512 ? 512 : full > 0xFFFFFFFFull ? 0xFFFFFFFFull : full);
         const uint32_t gate_limit = (uint32_t)(n / 4);
         PC_LAUNCH("pc_c3_plan", pc_c3_plan, plan_grid, dim3(PC_G_PLAN_TPB), (hipStream_t)stream, d_cell_start, x_lo, x_hi, queue,
-                  seg_cap, full_pencil);
+                  seg_cap, full_pencil, fgate);
         // as many workgroups as are resident at once (registers and LDS decide: asked of the runtime, once)
         static int resident_on[64];               // per device ordinal (count_queue has checked the range)
         int dev = 0;
@@ -657,6 +686,41 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
     return PC_OK;
 }
 
+extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t *d_cell_start,
+                                      uint64_t n, int x_lo, int x_hi, uint64_t *d_npairs,
+                                      void *stream)
+{
+    return count_sorted(d_sorted_xyz, d_cell_start, n, x_lo, x_hi, d_npairs, stream, nullptr);
+}
+
+// Whether a whole-path call tries the fused pair test (level Z inside the pair test, pc_count_fused.h): asked
+// for by name, or by density under the default choice -- from 2/3 of a point per cell, where the windowed kernels
+// start to pay, up to 1.9, beyond which a pencil neighbourhood of a uniform input may exceed the kernel's LDS.
+static bool fused_wanted(uint64_t n, int x_lo, int x_hi)
+{
+    const int v = g_variant_count;
+    if (g_variant_bin != 1 || n == 0 || x_lo == x_hi) return false;
+    if (v == 7) return true;
+    if (v != 4) return false;
+    const uint64_t cells = (uint64_t)(x_hi < PC_NLAYERS ? x_hi - x_lo + 1 : x_hi - x_lo) * PC_NLAYERS * PC_NLAYERS;
+    return n * 3 >= cells * 2 && n * 10 <= cells * 19;
+}
+
+static const uint32_t *fused_gate_words(void *d_workspace, uint64_t n) { return carve_lds_ws(d_workspace, n).big_count + 2; }
+
+// The fused pair test on the level-Y output that bin_lds left in the workspace.  ADDS to *d_npairs and, if
+// asked, to *d_ntests; returns at once (on the device) if a neighbourhood exceeds its capacity.
+static int count_fused(void *d_workspace, uint64_t n, int x_lo, int x_hi, uint64_t *d_npairs, uint64_t *d_ntests,
+                       int32_t *d_status, hipStream_t s)
+{
+    const pc_lds_ws w = carve_lds_ws(d_workspace, n);
+    const dim3 grid((unsigned)(x_hi - x_lo) * PC_NLAYERS);
+    PC_LAUNCH("pc_c7_count_fused", pc_c7_count_fused<true>, grid, dim3(PC_F_TPB), s, w.tmp, w.pencil_start, x_lo, x_hi,
+              w.big_count + 2, (unsigned long long *)d_npairs, (unsigned long long *)d_ntests, d_status, t_geo);
+    PC_HIP(hipGetLastError());
+    return PC_OK;
+}
+
 extern "C" int pc_count_tests_device(const uint32_t *d_cell_start, int x_lo, int x_hi,
                                      uint64_t *d_ntests, void *stream)
 {
@@ -680,11 +744,18 @@ extern "C" int pc_count_pairs_device(const float *d_xyz, uint64_t n, int x_lo, i
     int rc = check_slab("pc_count_pairs_device", x_lo, x_hi);
     if (rc) return rc;
     // home layers [x_lo, x_hi) and the halo layer x_hi are all the pair test reads
+    const bool fused = fused_wanted(n, x_lo, x_hi);
     rc = bin_layers(d_xyz, n, d_sorted_xyz, d_cell_start, d_workspace, workspace_bytes, d_status, stream, x_lo,
-                    x_hi < PC_NLAYERS ? x_hi : PC_NBB - 1);        // the last slab also gets the empty padding layers
+                    x_hi < PC_NLAYERS ? x_hi : PC_NBB - 1,         // the last slab also gets the empty padding layers
+                    nullptr, x_lo, x_hi, fused);
     if (rc) return rc;
     PC_HIP(hipMemsetAsync(d_npairs, 0, sizeof(uint64_t), (hipStream_t)stream));
-    return pc_count_sorted_device(d_sorted_xyz, d_cell_start, n, x_lo, x_hi, d_npairs, stream);
+    if (fused) {
+        rc = count_fused(d_workspace, n, x_lo, x_hi, d_npairs, nullptr, d_status, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return count_sorted(d_sorted_xyz, d_cell_start, n, x_lo, x_hi, d_npairs, stream,
+                        fused ? fused_gate_words(d_workspace, n) : nullptr);
 }
 
 extern "C" int pc_count_pairs_geometry_device(const pc_geometry *g, const float *d_xyz, uint64_t n, int x_lo, int x_hi,
@@ -1171,31 +1242,50 @@ static int finish_work(pc_context *c)
         explicit device_turn(pthread_mutex_t *mm) : m(mm) { pthread_mutex_lock(m); }
         ~device_turn() { pthread_mutex_unlock(m); }
     } turn(&g_finish_lock[c->device & 63]);
+    // whatever way this function is left, nothing it queued may still run when the lock is released and the
+    // buffers are freed (declared last: destroyed first)
+    struct drained {
+        hipStream_t st;
+        ~drained() { (void)hipStreamSynchronize(st); }
+    } drain{s};
     // the histogram kernels of the appends ran on the null stream or on streams their callers have synchronised
     // (pc_append_device waits for its copy AND the kernel queued behind it): this stream is ordered behind them
     const bool counted = c->layers_counted && g_variant_bin == 1;
     PC_HIP(hipMemsetAsync(b.res, 0, 16, s));
     if (!counted) PC_HIP(hipMemsetAsync(c->d_status, 0, 4, s));      // (the counts taken under another geometry may have flagged points)
     PC_HIP(hipEventRecord(b.ev[0], s));
+    const bool fused = fused_wanted(n, c->x_lo, c->x_hi);
     int rc = bin_layers(c->d_xyz, n, b.sorted, b.table, b.ws, wsb, c->d_status, s, c->x_lo,
-                        c->x_hi < PC_NLAYERS ? c->x_hi : PC_NBB - 1, counted ? c->d_layer_count : nullptr);
+                        c->x_hi < PC_NLAYERS ? c->x_hi : PC_NBB - 1, counted ? c->d_layer_count : nullptr, c->x_lo, c->x_hi, fused);
     if (rc) return rc;
     PC_HIP(hipEventRecord(b.ev[1], s));
     // a point outside the grid leaves the sorted array and the table incomplete: stop before the pair test
     int32_t host_status = 0;
+    uint32_t gate[2] = {1, 0};                       // [0] largest pencil neighbourhood, [1] the fused kernel's capacity
     PC_HIP(hipMemcpyAsync(&host_status, c->d_status, 4, hipMemcpyDeviceToHost, s));
+    if (fused) PC_HIP(hipMemcpyAsync(gate, fused_gate_words(b.ws, n), 8, hipMemcpyDeviceToHost, s));
     PC_HIP(hipStreamSynchronize(s));
     if (host_status & 1)
         return pc_fail(PC_ERR_DOMAIN, "a coordinate lies outside the reference's domain (-10,10)");
     PC_HIP(hipEventRecord(b.ev[2], s));
-    rc = pc_count_sorted_device(b.sorted, b.table, n, c->x_lo, c->x_hi, b.res, s);
-    if (rc) return rc;
-    PC_HIP(hipEventRecord(b.ev[3], s));
-    rc = pc_count_tests_device(b.table, c->x_lo, c->x_hi, b.res + 1, s);
-    if (rc) return rc;
+    if (gate[0] <= gate[1]) {
+        // level Z inside the pair test: no sorted array, no table; the kernel counts the reference's tests as well
+        rc = count_fused(b.ws, n, c->x_lo, c->x_hi, b.res, b.res + 1, c->d_status, s);
+        if (rc) return rc;
+        PC_HIP(hipEventRecord(b.ev[3], s));
+    } else {
+        rc = count_sorted(b.sorted, b.table, n, c->x_lo, c->x_hi, b.res, s, nullptr);
+        if (rc) return rc;
+        PC_HIP(hipEventRecord(b.ev[3], s));
+        rc = pc_count_tests_device(b.table, c->x_lo, c->x_hi, b.res + 1, s);
+        if (rc) return rc;
+    }
     uint64_t host_res[2];
     PC_HIP(hipMemcpyAsync(host_res, b.res, 16, hipMemcpyDeviceToHost, s));
+    PC_HIP(hipMemcpyAsync(&host_status, c->d_status, 4, hipMemcpyDeviceToHost, s));
     PC_HIP(hipStreamSynchronize(s));
+    if (host_status & 1)                             // (the fused kernel is the one that looks at z)
+        return pc_fail(PC_ERR_DOMAIN, "a coordinate lies outside the reference's domain (-10,10)");
     PC_HIP(hipEventElapsedTime(&c->ms[0], b.ev[0], b.ev[1]));
     PC_HIP(hipEventElapsedTime(&c->ms[1], b.ev[2], b.ev[3]));
     c->npairs = (int64_t)host_res[0];

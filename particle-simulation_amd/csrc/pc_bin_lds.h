@@ -132,8 +132,9 @@ pc_l1_hist_x_range(const float *__restrict__ xyz, uint64_t first, uint64_t end, 
 __global__ void __launch_bounds__(512)
 pc_l2_scan_x(const uint32_t *__restrict__ layer_count, uint32_t *__restrict__ layer_start,
              uint32_t *__restrict__ layer_cursor, uint32_t *__restrict__ layer_tile,
-             uint32_t *__restrict__ tile_layer)
+             uint32_t *__restrict__ tile_layer, uint32_t *__restrict__ fused_cap_word, uint32_t fused_cap)
 {
+    if (threadIdx.x == 0) *fused_cap_word = fused_cap;   // second word of the switch that pc_fused_serves reads
     __shared__ uint32_t a[512], t[512];
     const int i = threadIdx.x;
     uint32_t rep[PC_L_NREP], c = 0;
@@ -203,21 +204,37 @@ pc_l4_hist_y(const uint16_t *__restrict__ ycell, const uint32_t *__restrict__ la
 // ---- L5: scan of the pencil counts, one workgroup per layer -------------------
 // A layer's pencils start where the layer starts (known from L2), so the 403
 // rows scan independently: pencil_start[i*403+j] = layer_start[i] + sum_{j'<j}.
+// The workgroups of the home layers [x_lo, x_hi) also look at the layer above and
+// record (atomic maximum into *max5) the largest number of points any home pencil
+// (i,j) of theirs has in its neighbourhood (i,j) (i,j+1) (i+1,j-1..j+1): what the
+// fused pair test must hold in LDS at once, and the switch between it and the classic kernels.
 __global__ void __launch_bounds__(512)
 pc_l5_scan_y(const uint32_t *__restrict__ pencil_count, const uint32_t *__restrict__ layer_start,
              uint32_t *__restrict__ pencil_start, uint32_t *__restrict__ pencil_cursor,
-             uint32_t wave_cap, uint32_t *__restrict__ big_count, uint32_t *__restrict__ big_list)
+             uint32_t wave_cap, uint32_t *__restrict__ big_count, uint32_t *__restrict__ big_list,
+             int x_lo, int x_hi, uint32_t *__restrict__ max5)
 {
-    __shared__ uint32_t a[512];
+    __shared__ uint32_t a[512], own[512], above[512], most;
     const int j = threadIdx.x, layer = blockIdx.x;
-    uint32_t rep[PC_L_NREP], c = 0;
+    uint32_t rep[PC_L_NREP], c = 0, cn = 0;
 #pragma unroll
     for (int g = 0; g < PC_L_NREP; g++) {
         rep[g] = j < PC_NBB ? pencil_count[g * PC_L_PSTRIDE + layer * PC_NBB + j] : 0u;
         c += rep[g];
     }
+    const bool home_layer = layer >= x_lo && layer < x_hi;
+    if (home_layer && layer + 1 < PC_NBB && j < PC_NBB)
+#pragma unroll
+        for (int g = 0; g < PC_L_NREP; g++) cn += pencil_count[g * PC_L_PSTRIDE + (layer + 1) * PC_NBB + j];
     a[j] = c;
+    own[j] = c;
+    above[j] = cn;
+    if (j == 0) most = 0;
     __syncthreads();
+    if (home_layer && j < PC_NLAYERS && c != 0) {
+        const uint32_t s5 = c + own[j + 1] + (j > 0 ? above[j - 1] : 0u) + cn + above[j + 1];
+        atomicMax(&most, s5);
+    }
     for (int off = 1; off < 512; off <<= 1) {
         uint32_t v = j >= off ? a[j - off] : 0u;
         __syncthreads();
@@ -236,6 +253,7 @@ pc_l5_scan_y(const uint32_t *__restrict__ pencil_count, const uint32_t *__restri
         }
     }
     if (layer == PC_NBB - 1 && j == PC_NBB) pencil_start[PC_L_NPENCILS] = ex;   // total
+    if (j == 0 && most != 0) atomicMax(max5, most);
 }
 
 #ifdef PC_L_TRACE
@@ -426,8 +444,10 @@ template <int CAP>
 __global__ void __launch_bounds__(PC_L7_WAVES * 64)
 pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
                    const uint32_t *__restrict__ pencil_start, uint32_t *__restrict__ table,
-                   uint32_t first_pencil, uint32_t end_pencil, int32_t *__restrict__ status, const pc_geom geo)
+                   uint32_t first_pencil, uint32_t end_pencil, int32_t *__restrict__ status, const pc_geom geo,
+                   const uint32_t *__restrict__ fgate)
 {
+    if (pc_fused_serves(fgate)) return;
     __shared__ uint32_t hist_all[PC_L7_WAVES][PC_L_BINS];
     constexpr int PPL = CAP / 64;                      // points per lane
     __shared__ __attribute__((aligned(16))) float stage_all[PC_L7_WAVES][CAP * 3 + 4];
@@ -518,8 +538,9 @@ pc_l7b_sort_big_pencils(const float *__restrict__ src, float *__restrict__ dst,
                         const uint32_t *__restrict__ big_count, const uint32_t *__restrict__ big_list,
                         uint32_t first_pencil, uint32_t end_pencil, uint32_t n_above, uint32_t n_upto,
                         uint32_t *__restrict__ huge_n, uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count,
-                        int32_t *__restrict__ status, const pc_geom geo)
+                        int32_t *__restrict__ status, const pc_geom geo, const uint32_t *__restrict__ fgate)
 {
+    if (pc_fused_serves(fgate)) return;
     constexpr int PC_L7B_PPT = PC_L7B_CAP / PC_L7B_TPB;
     __shared__ uint32_t hist[PC_L_BINS];
     __shared__ float stage[PC_L7B_CAP * 3];
@@ -599,8 +620,10 @@ __device__ __forceinline__ uint32_t pc_l7h_first_tile(uint32_t h)
 
 __global__ void __launch_bounds__(PC_L_TPB)
 pc_l7h_hist(const float *__restrict__ src, const uint32_t *__restrict__ pencil_start, const uint32_t *__restrict__ huge_n,
-            const uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count, int32_t *__restrict__ status, const pc_geom geo)
+            const uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count, int32_t *__restrict__ status, const pc_geom geo,
+            const uint32_t *__restrict__ fgate)
 {
+    if (pc_fused_serves(fgate)) return;
     __shared__ uint32_t h_lds[PC_L_BINS];
     const uint32_t entries = *huge_n;
     bool bad = false;
@@ -635,8 +658,10 @@ pc_l7h_hist(const float *__restrict__ src, const uint32_t *__restrict__ pencil_s
 
 __global__ void __launch_bounds__(64)
 pc_l7h_scan(const uint32_t *__restrict__ pencil_start, const uint32_t *__restrict__ huge_n, const uint32_t *__restrict__ huge_list,
-            const uint32_t *__restrict__ huge_count, uint32_t *__restrict__ huge_cursor, uint32_t *__restrict__ table)
+            const uint32_t *__restrict__ huge_count, uint32_t *__restrict__ huge_cursor, uint32_t *__restrict__ table,
+            const uint32_t *__restrict__ fgate)
 {
+    if (pc_fused_serves(fgate)) return;
     __shared__ uint32_t hist[PC_L_BINS];
     const uint32_t entries = *huge_n;
     for (uint32_t h = blockIdx.x; h < entries; h += gridDim.x) {
@@ -657,8 +682,9 @@ pc_l7h_scan(const uint32_t *__restrict__ pencil_start, const uint32_t *__restric
 __global__ void __launch_bounds__(PC_L_PTPB)
 pc_l7h_partition(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ pencil_start,
                  const uint32_t *__restrict__ huge_n, const uint32_t *__restrict__ huge_list,
-                 uint32_t *__restrict__ huge_cursor, const pc_geom geo)
+                 uint32_t *__restrict__ huge_cursor, const pc_geom geo, const uint32_t *__restrict__ fgate)
 {
+    if (pc_fused_serves(fgate)) return;
     __shared__ float buf[PC_L_TILE * 3];              // the tile sorted by cell
     __shared__ uint16_t bin_of[PC_L_TILE];
     __shared__ uint32_t hist[PC_L_BINS], lstart[PC_L_BINS], delta[PC_L_BINS];

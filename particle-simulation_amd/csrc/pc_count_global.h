@@ -58,8 +58,9 @@ __device__ __forceinline__ uint32_t pc_count_one_home(const float *__restrict__ 
 __global__ void __launch_bounds__(256)
 pc_c0_count_global(const float *__restrict__ pts, const uint32_t *__restrict__ T,
                    uint32_t c_lo, uint32_t c_hi,   // home keys [c_lo, c_hi)
-                   unsigned long long *__restrict__ out, const pc_geom geo)
+                   unsigned long long *__restrict__ out, const pc_geom geo, const uint32_t *__restrict__ fgate)
 {
+    if (pc_fused_serves(fgate)) return;
     unsigned long long acc = 0;
     const uint32_t first = T[c_lo], last = T[c_hi];   // their slots in sorted order
     uint32_t stride = gridDim.x * blockDim.x;

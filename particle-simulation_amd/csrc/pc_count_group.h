@@ -57,11 +57,13 @@
 // points in pencils far fuller than the average one (counted by the planning kernel): a clustered input.
 // The kernels of one pair-test call take it as the switch between their two divisions of the work (PC_GATE_*).
 #define PC_G_DENSE_POINTS 296
+#define PC_G_SERVED 312               // set by the planning kernel when the fused pair test serves the call: every later kernel returns at once
 #define PC_GATE_ALWAYS 0
 #define PC_GATE_IF_EVEN 1            // run only if the dense points are at most the limit
 #define PC_GATE_IF_CLUSTERED 2       // run only if they are more
 __device__ __forceinline__ bool pc_gate_open(const unsigned int *queue, int gate, uint32_t limit)
 {
+    if (__builtin_amdgcn_readfirstlane(queue[PC_G_SERVED]) != 0) return false;
     if (gate == PC_GATE_ALWAYS) return true;
     const bool clustered = __builtin_amdgcn_readfirstlane(queue[PC_G_DENSE_POINTS]) > limit;
     return (gate == PC_GATE_IF_CLUSTERED) == clustered;
@@ -337,8 +339,13 @@ static_assert((unsigned long long)PC_G_PLAN_TARGET * PC_NLAYERS < 0xFFFFFFFFull,
 
 __global__ void __launch_bounds__(PC_G_PLAN_TPB)
 pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__restrict__ work, uint32_t seg_cap,
-           uint32_t full_pencil)    // a pencil with more points than this counts as dense (several times the average)
+           uint32_t full_pencil,    // a pencil with more points than this counts as dense (several times the average)
+           const uint32_t *__restrict__ fgate)
 {
+    if (pc_fused_serves(fgate)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) work[PC_G_SERVED] = 1;
+        return;
+    }
     __shared__ unsigned long long ends[PC_G_PLAN_PENCILS][PC_G_PLAN_STEPS];   // per 64 cells: the cells that close a segment
     __shared__ uint32_t seg_n[PC_G_PLAN_PENCILS], seg_at[PC_G_PLAN_PENCILS];
     __shared__ unsigned long long to_plan;
@@ -809,7 +816,7 @@ pc_c3_heavy(const float *__restrict__ pts, const uint32_t *__restrict__ T, const
 {
     static_assert(PC_G_HEAVY_CHUNK == 2 * PC_HV_TPB && PC_HV_TILE == PC_G_HEAVY_CHUNK, "two home particles per thread, home chunk = one tile");
     const uint32_t items = min(work[PC_G_HEAVY_COUNT], heavy_cap);
-    if (items == 0) return;
+    if (items == 0 || work[PC_G_SERVED] != 0) return;
     __shared__ pc_hv4 tile[PC_HV_TILE];
     struct pt3 { float x, y, z; };
     const pt3 *P = reinterpret_cast<const pt3 *>(pts);

@@ -68,6 +68,15 @@ __device__ __forceinline__ bool pc_in_grid(int i, int j, int k, const pc_geom &g
     return ((unsigned)i < nc) & ((unsigned)j < nc) & ((unsigned)k < nc);
 }
 
+// A call of the whole path may be served by the fused pair test (pc_count_fused.h), which needs neither
+// the z-sorted array nor the table: fgate[0] = largest pencil neighbourhood of the slab (written by the
+// level-Y scan), fgate[1] = what the fused kernel holds.  The kernels of the classic route return at once
+// when it serves the call (fgate == nullptr: there is no such alternative in this call).
+__device__ __forceinline__ bool pc_fused_serves(const uint32_t *fgate)
+{
+    return fgate != nullptr && fgate[0] <= fgate[1];
+}
+
 // Distance predicate: reference main.c:85-91 (dpps imm 0x71) and main.c:165.
 // Three products, summed as (dx*dx + dy*dy) + dz*dz, every step a separately
 // rounded binary32 operation -- __fmul_rn/__fadd_rn are never contracted into
