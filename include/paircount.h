@@ -194,15 +194,14 @@ int pc_count_tests_device(const uint32_t *d_cell_start, int x_lo, int x_hi,
                           uint64_t *d_ntests, void *stream);
 
 /* Whole hot path on device-resident input: keys, binning, pair test;
-   *d_npairs is overwritten with the count.  d_sorted_xyz / d_cell_start (sized
-   as above) are WORK AREAS of this call: on moderately filled grids (about 2/3
-   of a point to 2 points per cell) the last binning level runs inside the pair
-   test's LDS and neither the z-sorted array nor the table is written at all; on
-   other inputs they hold pc_bin_device's results for the x layers x_lo .. x_hi
-   (the slab and its halo layer, all the pair test reads).  Which of the two
-   happened is decided on the device.  Callers that want the table call
-   pc_bin_device, or pc_set_variant("count", 5) first (windowed pair test on the
-   sorted array, the table always written). */
+   *d_npairs is overwritten with the count.  d_sorted_xyz / d_cell_start as
+   above (outputs, kept for inspection), except that they are complete only for
+   the x layers x_lo .. x_hi (the slab and its halo layer, all the pair test
+   reads; with x_hi = 400 also the two empty padding layers, i.e. to the end of
+   the table).  Under pc_set_variant("count", 7) they are work areas only: the
+   last binning level then runs inside the pair test's LDS wherever every pencil
+   neighbourhood of the slab fits it (decided on the device), and neither the
+   z-sorted array nor the table is written. */
 int pc_count_pairs_device(const float *d_xyz, uint64_t n, int x_lo, int x_hi,
                           float *d_sorted_xyz, uint32_t *d_cell_start,
                           void *d_workspace, size_t workspace_bytes,

@@ -110,8 +110,12 @@ def _check(rc):
         raise PairCountError(rc, lib().pc_last_error().decode())
 
 
+_variants = {}          # what set_variant() was last given, per name (the library has no getter)
+
+
 def set_variant(name, value):
     _check(lib().pc_set_variant(name.encode(), int(value)))
+    _variants[name] = int(value)
 
 
 def profile_enable(on=True):
@@ -237,10 +241,10 @@ class DeviceStages:
     synchronises or allocates, so the sequence can be timed with events on the
     current torch stream.
 
-    count_pairs() may leave the sorted array and the table unwritten (the library
-    then ran its last binning level inside the pair test); `.sorted`, `.table`,
-    count_sorted() and count_tests() bin the same points again first when that
-    may have happened, so they always see pc_bin_device's results.
+    Under set_variant("count", 7) count_pairs() may leave the sorted array and the
+    table unwritten (the library then runs its last binning level inside the pair
+    test); `.sorted`, `.table`, count_sorted() and count_tests() bin the same points
+    again first when that may have happened, so they always see pc_bin_device's results.
     """
 
     def __init__(self, capacity, device="cuda:0"):
@@ -332,7 +336,7 @@ class DeviceStages:
                                                         self._sorted.data_ptr(), self._table.data_ptr(), self.ws.data_ptr(),
                                                         self.ws_bytes, self.result.data_ptr(), self.status.data_ptr(),
                                                         self._stream()))
-        self._unbinned = (xyz, geometry)
+        self._unbinned = (xyz, geometry) if _variants.get("count") == 7 else None
         return n
 
     def pairs(self):

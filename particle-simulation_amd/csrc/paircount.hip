@@ -124,7 +124,7 @@ static std::atomic<int> g_variant_bin{1};     // 0 = atomic counting sort, 1 = L
 // 5 = merged single-run windows (variant 3's kernel for heavy pencils and what 5 defers),
 // 7 = level Z fused into the pair test (whole-path entry points only; the z sort and variant 4's choice take
 //     over, decided on the device, when a pencil neighbourhood exceeds the fused kernel's capacity),
-// 4 = by density: 0 below 2/3 of a point per cell of the slab on average, 7 up to 1.9 (whole-path entry points), else 5
+// 4 = by density: 0 below 2/3 of a point per cell of the slab on average, else 5
 static std::atomic<int> g_variant_count{4};
 static std::atomic<int> g_heavy{PC_G_HEAVY_CAP};    // capacity of the list of over-full cells' home-particle chunks (0: never listed)
 static std::atomic<int> g_segments{PC_G_SEG_CAP};  // capacity of the heavy-pencil segment list (0: pencils are never cut)
@@ -294,7 +294,7 @@ static constexpr size_t lds_ws_counters(uint64_t n)
 {
     return (size_t)PC_L_NREP * PC_L_BINS + (size_t)PC_L_NREP * PC_L_PSTRIDE + PC_L_BINS + (size_t)PC_L_NREP * PC_L_BINS + PC_L_BINS +
            ((n + PC_L_TILE - 1) / PC_L_TILE + PC_L_BINS) + (PC_L_NPENCILS + 1) + (size_t)PC_L_NREP * PC_L_PSTRIDE +
-           8 + PC_L_NPENCILS + huge_rows(n) * (1 + 2 * (size_t)PC_L_BINS);
+           8 + PC_L_NPENCILS + huge_rows(n) * (1 + 2 * (size_t)PC_L_BINS) + PC_L_NPENCILS;
 }
 
 static constexpr size_t workspace_bytes_for(uint64_t n)
@@ -325,7 +325,8 @@ static pc_lds_ws carve_lds_ws(void *ws, uint64_t n)
     w.big_list = u;               u += PC_L_NPENCILS;
     w.huge_list = u;              u += huge_rows(n);
     w.huge_count = u;             u += huge_rows(n) * PC_L_BINS;
-    w.huge_cursor = u;
+    w.huge_cursor = u;            u += huge_rows(n) * PC_L_BINS;
+    w.fused_list = u;
     w.ycell = (uint16_t *)((char *)ws + align_up((size_t)n * 12 + 16, 256) + align_up(lds_ws_counters(n) * 4, 256));
     return w;
 }
@@ -693,17 +694,12 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
     return count_sorted(d_sorted_xyz, d_cell_start, n, x_lo, x_hi, d_npairs, stream, nullptr);
 }
 
-// Whether a whole-path call tries the fused pair test (level Z inside the pair test, pc_count_fused.h): asked
-// for by name, or by density under the default choice -- from 2/3 of a point per cell, where the windowed kernels
-// start to pay, up to 1.9, beyond which a pencil neighbourhood of a uniform input may exceed the kernel's LDS.
+// Whether a whole-path call tries the fused pair test (level Z inside the pair test, pc_count_fused.h): only when
+// asked for by name.  Measured at 1.56 points per cell it takes 2.6-2.75 ms against 2.06 ms for the z sort plus the
+// merged-window kernel, so the default choice by density does not include it.
 static bool fused_wanted(uint64_t n, int x_lo, int x_hi)
 {
-    const int v = g_variant_count;
-    if (g_variant_bin != 1 || n == 0 || x_lo == x_hi) return false;
-    if (v == 7) return true;
-    if (v != 4) return false;
-    const uint64_t cells = (uint64_t)(x_hi < PC_NLAYERS ? x_hi - x_lo + 1 : x_hi - x_lo) * PC_NLAYERS * PC_NLAYERS;
-    return n * 3 >= cells * 2 && n * 10 <= cells * 19;
+    return g_variant_count == 7 && g_variant_bin == 1 && n != 0 && x_lo != x_hi;
 }
 
 static const uint32_t *fused_gate_words(void *d_workspace, uint64_t n) { return carve_lds_ws(d_workspace, n).big_count + 2; }
@@ -715,8 +711,13 @@ static int count_fused(void *d_workspace, uint64_t n, int x_lo, int x_hi, uint64
 {
     const pc_lds_ws w = carve_lds_ws(d_workspace, n);
     const dim3 grid((unsigned)(x_hi - x_lo) * PC_NLAYERS);
-    PC_LAUNCH("pc_c7_count_fused", pc_c7_count_fused<true>, grid, dim3(PC_F_TPB), s, w.tmp, w.pencil_start, x_lo, x_hi,
-              w.big_count + 2, (unsigned long long *)d_npairs, (unsigned long long *)d_ntests, d_status, t_geo);
+    PC_LAUNCH("pc_c7_count_fused", pc_c7_count_fused, grid, dim3(PC_F_TPB), s, w.tmp, w.pencil_start, x_lo, x_hi,
+              w.big_count + 2, w.big_count + 4, w.fused_list, (unsigned long long *)d_npairs, (unsigned long long *)d_ntests,
+              d_status, t_geo);
+    // pencils with too many points in three consecutive blocks for a chunk of the kernel above (normally none)
+    PC_LAUNCH("pc_c7_count_fused_listed", pc_c7_count_fused_listed, dim3(256), dim3(PC_F_TPB), s, w.tmp, w.pencil_start,
+              w.big_count + 2, w.big_count + 4, w.fused_list, (unsigned long long *)d_npairs, (unsigned long long *)d_ntests,
+              d_status, t_geo);
     PC_HIP(hipGetLastError());
     return PC_OK;
 }

@@ -53,11 +53,13 @@ struct pc_lds_ws {
     uint32_t *pencil_start;   // [162409+1]
     uint32_t *pencil_cursor;  // [NREP][PSTRIDE]
     uint16_t *ycell;          // [N] y cell of every point of the level-X output (0xFFFF: outside the grid)
-    uint32_t *big_count;      // [8] (first word used) number of entries of big_list; zeroed with the counters
+    uint32_t *big_count;      // [8] zeroed with the counters: [0] entries of big_list, [1] of huge_list, [2] largest pencil neighbourhood of the
+                              //     home layers and [3] the fused pair test's capacity (pc_fused_serves), [4] entries of fused_list
     uint32_t *big_list;       // [162409] pencils with more points than one wave of L7 takes
     uint32_t *huge_list;      // [n/8192+2] pencils with more points than one workgroup of L7B takes (count: big_count[1])
     uint32_t *huge_count;     // [n/8192+2][404] their z-cell counts, then ...
     uint32_t *huge_cursor;    // [n/8192+2][404] ... the write cursors of their cells
+    uint32_t *fused_list;     // [162409] home pencils the fused pair test hands to its second instantiation
 };
 
 // ---- L1: histogram of x layers ---------------------------------------------

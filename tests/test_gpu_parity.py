@@ -48,7 +48,7 @@ def _cell_box(rng, n, lo_cell, hi_cell):
     return rng.uniform(lo, hi, (n, 3))
 
 
-VARIANTS = [(1, 4), (1, 5), (1, 3), (0, 0), (1, 1), (0, 2)]      # (binning variant, pair-test variant; 4 = chosen by density)
+VARIANTS = [(1, 4), (1, 5), (1, 3), (0, 0), (1, 1), (0, 2), (1, 7)]      # (binning variant, pair-test variant; 4 = chosen by density, 7 = level Z fused into the pair test)
 
 
 def gpu_count(psa, stages, torch_mod, xyz, x_lo=0, x_hi=400, bin_v=1, count_v=4):
