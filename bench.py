@@ -66,27 +66,75 @@ def kernel_bytes(name, n, layers):
     return table.get(name)
 
 
-def spawn_ranks(n):
-    """The parent of a self-launched multi-rank run: no torch, no HIP, only child processes."""
+def spawn_ranks(n, cmd=None, timeout_s=None, grace_s=5.0):
+    """The parent of a self-launched multi-rank run: no torch, no HIP, only child processes.
+
+    Every child is watched.  When one exits with a non-zero status -- a bad device ordinal, an import error,
+    a failed RCCL start-up -- the others would wait for it in init_process_group or a barrier until the
+    collective's own timeout; instead they are ended here (SIGTERM, SIGKILL after a grace period), the tail of
+    the failing rank's stderr is relayed, and the parent exits with that rank's status.  All ranks keep their
+    stderr (temporary files); rank 0's stdout carries the result line."""
+    import signal
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    cmd = cmd or [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    timeout_s = timeout_s or float(os.environ.get("PAIRCOUNT_BENCH_TIMEOUT", "1500"))
+    procs, errs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    worst = procs[0].returncode
-    for p in procs[1:]:
-        p.wait()
-        if p.returncode != 0 and worst == 0:
-            worst = p.returncode
+        errs.append(tempfile.TemporaryFile(mode="w+"))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=errs[r], text=True))
+
+    def tail(r, limit=3000):
+        errs[r].seek(0)
+        return errs[r].read()[-limit:]
+
+    def end_all():
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signal.SIGTERM)
+        t_end = time.time() + grace_s
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    t0 = time.time()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            rc = p.poll()
+            if rc is not None and rc != 0:
+                failed = (r, rc, "rank %d exited with status %d" % (r, rc))
+                break
+        if failed is None and time.time() - t0 > timeout_s:
+            failed = (0, 1, "no result within %.0f s" % timeout_s)
+        if failed is None:
+            time.sleep(0.05)
+    if failed is None:
+        for r, p in enumerate(procs):            # all have exited: any late non-zero status still counts
+            if p.returncode != 0:
+                failed = (r, p.returncode, "rank %d exited with status %d" % (r, p.returncode))
+                break
+    if failed is not None:
+        r, rc, what = failed
+        end_all()
+        sys.stderr.write("bench.py: %s; the other ranks were stopped.  Its stderr ends:\n%s\n" % (what, tail(r)))
+        sys.exit(rc if 0 < rc < 256 else 1)
+    out0 = procs[0].stdout.read()
+    for r in range(n):                           # warnings of the ranks, for the log
+        t = tail(r, 600)
+        if t.strip():
+            sys.stderr.write("[rank %d stderr] %s\n" % (r, t.strip()))
     sys.stdout.write(out0)
     sys.stdout.flush()
-    sys.exit(worst if worst >= 0 else 1)
+    sys.exit(0)
 
 
 def main():
@@ -111,6 +159,9 @@ def main():
                          "(a per-rank preview of the N-GPU line on a one-GPU box; not a bench result)")
     ap.add_argument("--event-period", type=int, default=4,
                     help="per-kernel HIP events around every k-th launch of each kernel inside the timed region (1: all)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="initialise the process group and run the 8-byte all-reduce also with ONE rank (the RCCL "
+                         "communicator, the int64 all_reduce and its teardown then execute on a one-GPU box)")
     ap.add_argument("--no-e2e-full", action="store_true",
                     help="skip the full-size end-to-end leg of cpu_baseline (reference program and the product's host "
                          "program on the whole workload written as a text file)")
@@ -130,13 +181,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
+    if os.environ.get("PAIRCOUNT_TEST_FAIL_RANK") == str(rank):      # (launcher test: a rank that dies at start-up)
+        sys.exit("bench.py: rank %d fails on request (PAIRCOUNT_TEST_FAIL_RANK)" % rank)
+    collective = world > 1 or args.force_collective
     if args.backend == "nccl" and world > torch.cuda.device_count():
         sys.exit("bench.py: %d ranks but %d GPUs; --backend gloo rehearses more ranks than GPUs" % (world, torch.cuda.device_count()))
     dev_index = local_rank % torch.cuda.device_count() if args.backend == "gloo" else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -193,7 +252,7 @@ def main():
 
     def step():
         st.count_pairs(xyz, x_lo, x_hi)          # keys + binning + pair test, one C-ABI call
-        if world > 1:
+        if collective:
             total.copy_(st.result[0:1])      # (gloo rehearsal: a synchronising copy to host)
             dist.all_reduce(total)           # the path's only collective: one 8-byte sum
 
@@ -203,19 +262,30 @@ def main():
     # per-kernel HIP events on every 4th step of the timed region (on every step they cost 0.15 ms of a 3.7 ms
     # step: 34 event records); PAIRCOUNT_BENCH_NO_EVENTS=1 switches them off to measure just that
     psa.profile_enable(0 if os.environ.get("PAIRCOUNT_BENCH_NO_EVENTS") else args.event_period)
-    if world > 1:
+    if collective:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if collective:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     psa.profile_enable(False)
     prof = psa.profile_read()
+    # the collective by itself: the copy of the count and the 8-byte sum, K times, on an otherwise idle device
+    all_reduce_ms = None
+    if collective:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            total.copy_(st.result[0:1])
+            dist.all_reduce(total)
+        torch.cuda.synchronize()
+        all_reduce_ms = (time.perf_counter() - t1) / args.steps * 1e3
 
     pairs_local = st.pairs()
     st.count_tests(x_lo, x_hi)
@@ -228,7 +298,7 @@ def main():
     mine = torch.tensor([rank, x_lo, x_hi, n, tests_local, pairs_local, elapsed / args.steps * 1e3,
                          phase_ms(False), phase_ms(True)], dtype=torch.float64, device=red_device)
     rows = [torch.zeros_like(mine) for _ in range(world)]
-    if world > 1:
+    if collective:
         dist.all_gather(rows, mine)
     else:
         rows = [mine]
@@ -238,7 +308,7 @@ def main():
     pairs = sum(r["pairs"] for r in ranks)
     tests = sum(r["tests"] for r in ranks)
     points_held = sum(r["points_held"] for r in ranks)
-    if world > 1:
+    if collective:
         assert int(total.item()) == pairs, "all-reduced count differs from the sum of rank counts"
     ms_per_step = max(r["ms_per_step"] for r in ranks)
     elapsed = ms_per_step * 1e-3 * args.steps
@@ -251,7 +321,7 @@ def main():
                 kernels[name] = {"avg_ms": ms / timed, "launches_per_step": launches / args.steps, "timed_launches": timed}
         if not kernels:            # events switched off (PAIRCOUNT_BENCH_NO_EVENTS: what the events themselves cost)
             print(json.dumps({"ms_per_step": ms_per_step, "events": False, "pairs": pairs, "tests": tests}))
-            if world > 1:
+            if collective:
                 dist.destroy_process_group()
             return
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches_per_step"])
@@ -300,11 +370,11 @@ def main():
             "unit": "pairs-tested/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             **({"preview_of_rank": args.as_rank} if args.as_rank and world == 1 else {}),
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling,
+            "ms_per_step": ms_per_step, "all_reduce_ms": all_reduce_ms, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "points": total_points, "points_held_incl_halo": points_held,
                        "cutoff": 0.05, "slabs": slabs, "slab_cuts": cuts, "seed": args.seed,
-                       "generator": args.generate, "generator_s": round(t_gen, 2), "backend": args.backend if world > 1 else None},
+                       "generator": args.generate, "generator_s": round(t_gen, 2), "backend": args.backend if collective else None},
             "pairs": pairs, "tests": tests,
             "pairs_tested_per_s_pair_test_kernel_only": (tests_local / (cnt_ms * 1e-3)) if cnt_ms else None,
             "binning_ms": bin_ms, "pair_test_ms": cnt_ms,
@@ -324,7 +394,7 @@ def main():
                 del xyz
                 out["cpu_baseline"]["end_to_end_full"] = end_to_end_full(ht, kind, args.seed, total_points, sigma, pairs)
         print(json.dumps(out))
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

@@ -230,6 +230,22 @@ static size_t g_text_blocks;
 static atomic_int g_gpu_lanes_busy;
 static int g_gpu_lanes;
 
+/* Whether some line of [p, e) is longer than the GPU tokenizer takes (256 bytes: the reference skips any number of
+   redundant decimals, parse.h:54-56, so such a line is legal).  A line that long holds a whole 128-byte-aligned
+   window without a line end; only then the exact length is looked at. */
+#define GPU_RECORD_MAX 256
+static int has_long_line(const char *p, const char *e)
+{
+    for (const char *q = p; q + 128 <= e; q += 128) {
+        if (memchr(q, '\n', 128)) continue;
+        const char *b = q, *a = q + 128;
+        while (b > p && b[-1] != '\n') b--;
+        while (a < e && *a != '\n') a++;
+        if (a - b >= GPU_RECORD_MAX) return 1;
+    }
+    return 0;
+}
+
 static void share_text_blocks(worker *w)
 {
     for (;;) {
@@ -239,7 +255,7 @@ static void share_text_blocks(worker *w)
         xyz_thread_range(w->file, w->size, (int)b, (int)g_text_blocks, &p, &e);
         if (p >= e) continue;
         int lane = 0;
-        if ((size_t)(e - p) <= TEXT_BLOCK_BYTES + TEXT_LINE_MAX) {
+        if ((size_t)(e - p) <= TEXT_BLOCK_BYTES + TEXT_LINE_MAX && !has_long_line(p, e)) {
             if (atomic_fetch_add(&g_gpu_lanes_busy, 1) < g_gpu_lanes) lane = 1;
             else atomic_fetch_sub(&g_gpu_lanes_busy, 1);
         }
@@ -383,7 +399,11 @@ int main(int argc, char **argv)
     double t0 = now_us();
     const char *file_name = NULL;
     int pthreads = 4, cthreads = 4;
-    int gpus = getenv("PAIRCOUNT_GPUS") ? atoi(getenv("PAIRCOUNT_GPUS")) : 1;
+    int gpus = 1;
+    if (getenv("PAIRCOUNT_GPUS") && (gpus = atoi(getenv("PAIRCOUNT_GPUS"))) <= 0) {
+        fprintf(stderr, "PAIRCOUNT_GPUS: need a positive count\n");
+        return -1;
+    }
     for (int i = 1; i < argc; i++) {
         if (argv[i][0] != '-') {
             printf("Unrecognized option \"%s\"\n", argv[i]);

@@ -51,6 +51,17 @@ def test_main_with_gpu_tokenizer(ht, oracle, golden_dir, tmp_path):
         f.write("1.000000 2.000000 3.000000\n" * 1000 + "12.5 1.0 1.0\n" + "1.000000 2.000000 3.000000\n" * 1000)
     r = subprocess.run([ht.MAIN_PATH, "-f", bad, "-p", "3"], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 255 and r.stdout == ""
+    # a record longer than the GPU tokenizer takes (the reference skips any number of redundant decimals,
+    # parse.h:54-56): its block is tokenized on the host, the count is that of the plain run
+    long_path = str(tmp_path / "long.xyz")
+    with open(long_path, "w") as f:
+        f.write("1.000000 2.000000 3.000000\n" * 700)
+        f.write("1.00" + "0" * 400 + " 2.000000 3.010000\n")
+        f.write("1.000000 2.000000 3.020000\n" * 700)
+    plain = subprocess.run([ht.MAIN_PATH, "-f", long_path, "-p", "3"], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([ht.MAIN_PATH, "-f", long_path, "-p", "3"], capture_output=True, text=True, timeout=120, env=env)
+    assert plain.returncode == 0 and r.returncode == 0, (plain.stderr, r.stderr)
+    assert r.stdout == plain.stdout == "%d\n" % (1401 * 1400 // 2)
 
 
 def test_main_on_generated_file_with_timer(ht, oracle, tmp_path):
@@ -125,6 +136,19 @@ def test_main_multi_gpu_slabs(ht, oracle, golden_dir, tmp_path):
         r = subprocess.run([ht.MAIN_PATH, "-f", fp, "-g", "2"], capture_output=True, text=True, timeout=60,
                            env=dict(os.environ, PAIRCOUNT_DEVICES="0,0"))
         assert r.returncode == 255 and "domain" in r.stderr
+
+
+def test_main_rejects_a_bad_gpu_count(ht, golden_dir):
+    """PAIRCOUNT_GPUS is held to the same rule as -g: a positive count, else the reference's failure status."""
+    path = os.path.join(golden_dir, "pairs12.xyz")
+    if not os.path.exists(path):
+        path = os.path.join(golden_dir, sorted(f for f in os.listdir(golden_dir) if f.endswith(".xyz"))[0])
+    for bad in ("0", "-1", "two"):
+        r = subprocess.run([ht.MAIN_PATH, "-f", path], capture_output=True, text=True, timeout=60,
+                           env=dict(os.environ, PAIRCOUNT_GPUS=bad))
+        assert r.returncode == 255 and "PAIRCOUNT_GPUS" in r.stderr and r.stdout == "", (bad, r.stderr)
+    r = subprocess.run([ht.MAIN_PATH, "-f", path, "-g", "0"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 255 and r.stdout == ""
 
 
 def test_main_slab_queue(ht, oracle, golden_dir, tmp_path):
