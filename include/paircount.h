@@ -229,10 +229,21 @@ int pc_selfcheck_cell_index_geometry_device(const pc_geometry *g, uint64_t *d_mi
    allocating call is made, by the library or through it.  n is limited to
    PC_NOALLOC_MAX_POINTS; more is PC_ERR_ARG.  Every call on a GPU uses that GPU's
    one array: calls that could overlap on one device (streams, host threads) race
-   and must be ordered by the caller; consecutive calls need no clean-up in
-   between.  The data's device must be current.  No counterpart in the reference
-   (its hash table is malloc'ed, hashmap.h:45-49,73-80). */
+   and must be ordered by the caller -- that includes every other pair-test entry
+   point (pc_finish, pc_count_pairs_device, pc_count_sorted_device), which share
+   the pair test's per-device work area with it; consecutive calls need no
+   clean-up in between.  The data's device must be current.
+   The first use on a device looks a few things up (the arrays' addresses, which
+   loads the code object; device properties; occupancy of the persistent kernels):
+   call pc_noalloc_prepare() once per device, with that device current, BEFORE a
+   stream capture or a section that must not touch the runtime -- after it, a call
+   is kernel launches and memsets on `stream` only and can be captured into a HIP
+   graph (with pc_profile_enable off: profiling records events).  Without the
+   prepare call the first pc_count_pairs_noalloc does the look-ups itself.
+   No counterpart in the reference (its hash table is malloc'ed,
+   hashmap.h:45-49,73-80). */
 #define PC_NOALLOC_MAX_POINTS 1048576ull
+int pc_noalloc_prepare(void);
 int pc_count_pairs_noalloc(const float *d_xyz, uint64_t n, int x_lo, int x_hi,
                            float *d_sorted_xyz, uint32_t *d_cell_start,
                            uint64_t *d_npairs, int32_t *d_status, void *stream);

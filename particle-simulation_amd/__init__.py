@@ -55,6 +55,7 @@ ABI = [
     ("pc_count_sorted_device", _i32, [_vp, _vp, _u64, _i32, _i32, _vp, _vp]),
     ("pc_count_tests_device", _i32, [_vp, _i32, _i32, _vp, _vp]),
     ("pc_count_pairs_device", _i32, [_vp, _u64, _i32, _i32, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    ("pc_noalloc_prepare", _i32, []),
     ("pc_count_pairs_noalloc", _i32, [_vp, _u64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     ("pc_geometry_default", _i32, [_vp]),
     ("pc_set_geometry", _i32, [_vp, _vp]),

@@ -272,19 +272,26 @@ static const uint64_t PC_MAX_POINTS = 0xFFFFFFF0ull;   // slots are uint32
 static constexpr uint32_t scan_tiles(uint64_t m) { return (uint32_t)((m + PC_SCAN_TILE - 1) / PC_SCAN_TILE); }
 static inline int grid_for(uint64_t n, int tpb, int cap);
 
-// Workgroups of `kernel` that are resident on the current device at once (the grid
-// of a kernel whose workgroups loop over a work list); `slot` caches the answer.
+// Grids of the kernels whose workgroups loop over a work list: as many workgroups as are resident on the
+// device at once (registers and LDS decide: asked of the runtime once per device, then cached -- the queries
+// load the code object and are not for a stream under capture, see pc_noalloc_prepare).
+struct launch_sizes {
+    int ready;
+    int l7b_small, l7b_large;       // pc_l7b_sort_big_pencils, both instantiations
+    int c3, c5, c6;                 // pc_c3_count_groups, pc_c5_count_merged, pc_c6_count_dense
+};
+static launch_sizes g_sizes[64];
+static pthread_mutex_t g_sizes_lock = PTHREAD_MUTEX_INITIALIZER;
+
 template <typename K>
-static int resident_blocks(K kernel, int tpb, int *slot)
+static int resident_blocks(K kernel, int tpb, int cus, int fallback_per_cu)
 {
-    if (*slot) return *slot;
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, tpb, 0) != hipSuccess || per_cu < 1)
-        return 1024;
-    return *slot = per_cu * prop.multiProcessorCount;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, tpb, 0) != hipSuccess || per_cu < 1) per_cu = fallback_per_cu;
+    return per_cu * cus;
 }
+
+static int launch_sizes_of_current_device(const launch_sizes **out);
 
 // uint32 counters of the LDS variant, after its N*12-byte temp array
 // pencils of more than PC_L7B_CAP_LARGE points there can be among n points (plus slack)
@@ -376,11 +383,13 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
     // pencils too big for a wave (listed by L5): one workgroup each, fixed grids walk the list, one per size class
     auto small = pc_l7b_sort_big_pencils<PC_L7B_CAP_SMALL, PC_L7B_TPB_SMALL>;
     auto large = pc_l7b_sort_big_pencils<PC_L7B_CAP_LARGE, PC_L7B_TPB_LARGE>;
-    static int small_grid, large_grid;            // (one device model per process is assumed for these two)
-    PC_LAUNCH("pc_l7b_sort_big_pencils", small, dim3(resident_blocks(small, PC_L7B_TPB_SMALL, &small_grid)), dim3(PC_L7B_TPB_SMALL), s, w.tmp, d_sorted, w.pencil_start, table,
+    const launch_sizes *sizes = nullptr;
+    const int rc_sizes = launch_sizes_of_current_device(&sizes);
+    if (rc_sizes) return rc_sizes;
+    PC_LAUNCH("pc_l7b_sort_big_pencils", small, dim3(sizes->l7b_small), dim3(PC_L7B_TPB_SMALL), s, w.tmp, d_sorted, w.pencil_start, table,
               w.big_count, w.big_list, first_pencil, end_pencil, 0u, (uint32_t)PC_L7B_CAP_SMALL,
               (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, d_status, t_geo, fgate);
-    PC_LAUNCH("pc_l7b_sort_bigger_pencils", large, dim3(resident_blocks(large, PC_L7B_TPB_LARGE, &large_grid)), dim3(PC_L7B_TPB_LARGE), s, w.tmp, d_sorted, w.pencil_start, table,
+    PC_LAUNCH("pc_l7b_sort_bigger_pencils", large, dim3(sizes->l7b_large), dim3(PC_L7B_TPB_LARGE), s, w.tmp, d_sorted, w.pencil_start, table,
               w.big_count, w.big_list, first_pencil, end_pencil, (uint32_t)PC_L7B_CAP_SMALL, (uint32_t)PC_L7B_CAP_LARGE,
               w.big_count + 1, w.huge_list, w.huge_count, d_status, t_geo, fgate);
     // pencils beyond a workgroup's capacity (listed just now): tile-parallel histogram, scan, partition
@@ -550,6 +559,33 @@ static int count_queue(unsigned int **out)
     return PC_OK;
 }
 
+static int launch_sizes_of_current_device(const launch_sizes **out)
+{
+    int dev = 0;
+    PC_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return pc_fail(PC_ERR_ARG, "device ordinal %d not supported", dev);
+    launch_sizes *z = &g_sizes[dev];
+    pthread_mutex_lock(&g_sizes_lock);
+    if (!z->ready) {
+        hipDeviceProp_t prop;
+        const hipError_t e = hipGetDeviceProperties(&prop, dev);
+        if (e != hipSuccess) {
+            pthread_mutex_unlock(&g_sizes_lock);
+            return pc_fail(PC_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+        }
+        const int cus = prop.multiProcessorCount;
+        z->l7b_small = resident_blocks(pc_l7b_sort_big_pencils<PC_L7B_CAP_SMALL, PC_L7B_TPB_SMALL>, PC_L7B_TPB_SMALL, cus, 4);
+        z->l7b_large = resident_blocks(pc_l7b_sort_big_pencils<PC_L7B_CAP_LARGE, PC_L7B_TPB_LARGE>, PC_L7B_TPB_LARGE, cus, 1);
+        z->c3 = resident_blocks(pc_c3_count_groups<true>, PC_G_WAVES * 64, cus, 16);
+        z->c5 = resident_blocks(pc_c5_count_merged, 64, cus, 16);
+        z->c6 = resident_blocks(pc_c6_count_dense, 64, cus, 16);
+        z->ready = 1;
+    }
+    pthread_mutex_unlock(&g_sizes_lock);
+    *out = z;
+    return PC_OK;
+}
+
 static int check_slab(const char *who, int x_lo, int x_hi)
 {
     if (x_lo < 0 || x_hi > PC_NLAYERS || x_lo > x_hi)
@@ -599,33 +635,15 @@ static int count_sorted(const float *d_sorted_xyz, const uint32_t *d_cell_start,
         const uint32_t gate_limit = (uint32_t)(n / 4);
         PC_LAUNCH("pc_c3_plan", pc_c3_plan, plan_grid, dim3(PC_G_PLAN_TPB), (hipStream_t)stream, d_cell_start, x_lo, x_hi, queue,
                   seg_cap, full_pencil, fgate);
-        // as many workgroups as are resident at once (registers and LDS decide: asked of the runtime, once)
-        static int resident_on[64];               // per device ordinal (count_queue has checked the range)
-        int dev = 0;
-        PC_HIP(hipGetDevice(&dev));
-        int resident = resident_on[dev];
-        if (!resident) {
-            int per_cu = 0;
-            hipDeviceProp_t prop;
-            PC_HIP(hipGetDeviceProperties(&prop, dev));
-            PC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pc_c3_count_groups<true>, PC_G_WAVES * 64, 0));
-            resident = (per_cu > 0 ? per_cu : 16) * prop.multiProcessorCount;
-            resident_on[dev] = resident;
-        }
+        const launch_sizes *sizes = nullptr;
+        rc2 = launch_sizes_of_current_device(&sizes);
+        if (rc2) return rc2;
+        const int resident = sizes->c3;
         const int want = resident, most = ((x_hi - x_lo) * PC_NLAYERS + PC_G_WAVES - 1) / PC_G_WAVES;
         if (variant == 5) {
             // the merged-window kernel takes every pencil the planner left whole; what it cannot process goes on the
             // segment list, which the group kernel then works off together with the planned segments
-            static int resident5_on[64];
-            int r5 = resident5_on[dev];
-            if (!r5) {
-                int per_cu = 0;
-                hipDeviceProp_t prop;
-                PC_HIP(hipGetDeviceProperties(&prop, dev));
-                PC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pc_c5_count_merged, 64, 0));
-                r5 = (per_cu > 0 ? per_cu : 16) * prop.multiProcessorCount;
-                resident5_on[dev] = r5;
-            }
+            const int r5 = sizes->c5;
             // every wave the same number of pencils: with 3.3 pencils per resident wave (a slab of an 8-GPU run) a
             // quarter of the waves would take a fourth one while the others idle; fewer waves, each a little faster
             // for the free share of its SIMD, finish the same four rounds sooner
@@ -644,16 +662,7 @@ static int count_sorted(const float *d_sorted_xyz, const uint32_t *d_cell_start,
         if (variant == 5) {
             if (g_dense.load()) {
                 // planned segments and pencil rests: cells filled well enough for the candidates-in-registers form
-                static int resident6_on[64];
-                int r6 = resident6_on[dev];
-                if (!r6) {
-                    int per_cu = 0;
-                    hipDeviceProp_t prop;
-                    PC_HIP(hipGetDeviceProperties(&prop, dev));
-                    PC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pc_c6_count_dense, 64, 0));
-                    r6 = (per_cu > 0 ? per_cu : 16) * prop.multiProcessorCount;
-                    resident6_on[dev] = r6;
-                }
+                const int r6 = sizes->c6;
                 PC_LAUNCH("pc_c6_count_dense", pc_c6_count_dense, dim3(r6), dim3(64), (hipStream_t)stream,
                           d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap, PC_GATE_IF_EVEN, gate_limit,
                           (unsigned long long *)d_npairs, t_geo.d2max);
@@ -801,6 +810,21 @@ static int scratch_of_current_device(unsigned char **out)
     pthread_mutex_unlock(&g_queue_lock);
     *out = p;
     return PC_OK;
+}
+
+// Everything pc_count_pairs_noalloc looks up once per device -- the addresses of the two built-in arrays
+// (hipGetSymbolAddress also loads the code object), the device's properties and the resident grid sizes of the
+// persistent kernels (occupancy queries) -- done ahead of time, so that the call itself consists of nothing but
+// kernel launches and memsets on the caller's stream.
+extern "C" int pc_noalloc_prepare(void)
+{
+    unsigned char *ws = nullptr;
+    unsigned int *queue = nullptr;
+    const launch_sizes *sizes = nullptr;
+    int rc = scratch_of_current_device(&ws);
+    if (!rc) rc = count_queue(&queue);
+    if (!rc) rc = launch_sizes_of_current_device(&sizes);
+    return rc;
 }
 
 extern "C" int pc_count_pairs_noalloc(const float *d_xyz, uint64_t n, int x_lo, int x_hi,

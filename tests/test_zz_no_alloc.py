@@ -91,3 +91,69 @@ def test_noalloc_entry_point_equals_workspace_entry_point(psa, oracle):
                                   vp(bufs["table"].data_ptr()), vp(bufs["result"].data_ptr()),
                                   vp(bufs["status"].data_ptr()), vp(0))
     assert rc == -1 and b"exceed" in L.pc_last_error()
+
+
+def _hip():
+    """The HIP runtime the library itself is linked against (already loaded by torch)."""
+    return ctypes.CDLL("libamdhip64.so")
+
+
+def test_noalloc_allocates_nothing_and_can_be_captured(psa, oracle):
+    """After pc_noalloc_prepare(): free device memory is the same before and after a call, and a call recorded
+    into a HIP graph (stream capture) gives the same count when the graph is launched -- twice, on new input in
+    the same buffers."""
+    import torch
+    L, hip = psa.lib(), _hip()
+    vp = ctypes.c_void_p
+    rng = np.random.default_rng(77)
+    pts = np.concatenate([rng.uniform(-9.999, 9.999, (300_000, 3)), rng.normal(2.0, 0.1, (100_000, 3))]).astype(np.float32)
+    other = rng.normal(-3.0, 0.2, (400_000, 3)).astype(np.float32)
+    want, want_other = oracle.count_pairs(pts)[0], oracle.count_pairs(other)[0]
+    n = len(pts)
+    xyz = torch.from_numpy(pts).to("cuda:0")
+    srt = torch.empty((n, 3), dtype=torch.float32, device="cuda:0")
+    table = torch.empty(TABLE_LEN, dtype=torch.int32, device="cuda:0")
+    result = torch.zeros(2, dtype=torch.int64, device="cuda:0")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    assert L.pc_noalloc_prepare() == 0, L.pc_last_error()
+    L.pc_profile_enable(0)
+    stream = torch.cuda.Stream()
+    args = (vp(xyz.data_ptr()), n, 0, 400, vp(srt.data_ptr()), vp(table.data_ptr()), vp(result.data_ptr()),
+            vp(status.data_ptr()), vp(stream.cuda_stream))
+
+    def free_bytes():
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+
+    assert L.pc_count_pairs_noalloc(*args) == 0, L.pc_last_error()      # (warm: the code object's kernels have run once)
+    stream.synchronize()
+    before = free_bytes()
+    assert L.pc_count_pairs_noalloc(*args) == 0, L.pc_last_error()
+    stream.synchronize()
+    assert free_bytes() == before
+    assert int(result[0].item()) == want and int(status.item()) == 0
+
+    # the same call under stream capture: nothing in it may be refused, and nothing runs until the graph is launched
+    result.zero_()
+    torch.cuda.synchronize()
+    graph, graph_exec = vp(), vp()
+    assert hip.hipStreamBeginCapture(vp(stream.cuda_stream), 0) == 0          # hipStreamCaptureModeGlobal
+    rc = L.pc_count_pairs_noalloc(*args)
+    end = hip.hipStreamEndCapture(vp(stream.cuda_stream), ctypes.byref(graph))
+    assert rc == 0, L.pc_last_error()
+    assert end == 0 and graph.value
+    assert int(result[0].item()) == 0                                          # captured, not executed
+    assert hip.hipGraphInstantiate(ctypes.byref(graph_exec), graph, None, None, 0) == 0
+    try:
+        assert hip.hipGraphLaunch(graph_exec, vp(stream.cuda_stream)) == 0
+        stream.synchronize()
+        assert int(result[0].item()) == want and int(status.item()) == 0
+        xyz.copy_(torch.from_numpy(other))                                     # new points, same buffers, same graph
+        torch.cuda.synchronize()
+        assert hip.hipGraphLaunch(graph_exec, vp(stream.cuda_stream)) == 0
+        stream.synchronize()
+        assert int(result[0].item()) == want_other and int(status.item()) == 0
+    finally:
+        hip.hipGraphExecDestroy(graph_exec)
+        hip.hipGraphDestroy(graph)
