@@ -612,7 +612,6 @@ static int count_sorted(const float *d_sorted_xyz, const uint32_t *d_cell_start,
         const uint64_t cells = (uint64_t)(x_hi < PC_NLAYERS ? x_hi - x_lo + 1 : x_hi - x_lo) * PC_NLAYERS * PC_NLAYERS;
         variant = n * 3 < cells * 2 ? 0 : 5;
     }
-    if (variant == 5 && n * 12 > 0xFFFFFFFFull) variant = 3;       // variant 5 addresses the sorted array by 32-bit byte offsets
     if (variant == 0) {
         uint32_t c_lo = (uint32_t)x_lo * PC_NBB2, c_hi = (uint32_t)x_hi * PC_NBB2;
         PC_LAUNCH("pc_c0_count_global", pc_c0_count_global, dim3(grid_for(n, 256, 4096)), dim3(256), (hipStream_t)stream, d_sorted_xyz, d_cell_start, c_lo, c_hi,

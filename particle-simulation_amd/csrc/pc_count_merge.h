@@ -266,6 +266,15 @@ pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T
         const uint32_t home_lo = T[tb[0]], home_hi = T[tb[0] + PC_NLAYERS];
         int z0 = 0;
         uint32_t done = skip ? home_hi : home_lo;          // first home slot not yet processed
+        // The gather list holds 32-bit byte offsets from the pencil's first point; every point a window gathers lies
+        // between it and the end of layer i+1.  Should those two layers hold more than 4 GB of points (an input of
+        // over 3.5e8 points nearly all of which sit in two layers), the pencil goes to the segment list as a whole.
+        // (the last table entry of layer i+1: its always-empty padding pencil starts where the layer's points end)
+        const uint32_t reach = T[(uint32_t)(layer + 2) * PC_NBB2 - 1u] - home_lo;
+        if (!skip && done != home_hi && reach > 0xFFFFFFFFu / 12u) {
+            acc += pc_m_defer(pts, T, queue, seg_cap, pencil, 0, home_hi, lane, geo);
+            done = home_hi;
+        }
         // Lane t of a window starting at home cell z0 owns block S_{z0+t}: row 0 at cell z0+t, rows 1-4 at
         // cell z0+t-1.  (Cell -1 of a row reads the last, always empty, padding cell of the pencil before it;
         // cells past 402 are clamped to 402: empty as well.)  a0/a1 = start of that cell and of the next one.
@@ -326,20 +335,20 @@ pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T
                     const uint32_t spare = PC_M_SPARE;
 #pragma unroll
                     for (uint32_t v = 0; v < PC_M_UNROLL; v++) {
-                        L.src[v < n[0] ? ex + v : spare] = 12u * (s[0] + v);
+                        L.src[v < n[0] ? ex + v : spare] = 12u * (s[0] - home_lo + v);
                         L.home(v < nhome ? exh + v : PC_M_CAPH + 31) = ent + v;
                     }
                     for (uint32_t v = PC_M_UNROLL; __builtin_amdgcn_ballot_w64(v < n[0]) != 0; v++) {
-                        if (v < n[0]) L.src[ex + v] = 12u * (s[0] + v);
+                        if (v < n[0]) L.src[ex + v] = 12u * (s[0] - home_lo + v);
                         if (v < nhome) L.home(exh + v) = ent + v;
                     }
                     uint32_t o = ex + n[0];
 #pragma unroll
                     for (int r = 1; r < 5; r++) {
 #pragma unroll
-                        for (uint32_t v = 0; v < PC_M_UNROLL; v++) L.src[v < n[r] ? o + v : spare] = 12u * (s[r] + v);
+                        for (uint32_t v = 0; v < PC_M_UNROLL; v++) L.src[v < n[r] ? o + v : spare] = 12u * (s[r] - home_lo + v);
                         for (uint32_t v = PC_M_UNROLL; __builtin_amdgcn_ballot_w64(v < n[r]) != 0; v++)
-                            if (v < n[r]) L.src[o + v] = 12u * (s[r] + v);
+                            if (v < n[r]) L.src[o + v] = 12u * (s[r] - home_lo + v);
                         o += n[r];
                     }
                     // one step's worth of dead home entries: a slot of the never-matching tail, an empty run
@@ -347,14 +356,14 @@ pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T
                 }
                 pc_wave_lds_sync();
                 // ---- stage 2, lane = slot: gather the points through the list, straight into LDS (no registers)
-                const char *bytes = reinterpret_cast<const char *>(pts);
+                const char *bytes = reinterpret_cast<const char *>(pts) + 12ull * home_lo;   // (wave-uniform: scalar registers)
                 // (all list reads first, then the copies, last chunk first: see pc_merge_lds)
                 constexpr int NCHUNK = (PC_M_CAP + 63) / 64;
                 uint32_t off[NCHUNK];
 #pragma unroll
                 for (int c = 0; c < NCHUNK; c++) {
                     const uint32_t q = 64u * c + lane;
-                    off[c] = q < tot ? L.src[q] : 12u * home_lo;
+                    off[c] = q < tot ? L.src[q] : 0u;
                 }
 #pragma unroll
                 for (int c = NCHUNK - 1; c >= 0; c--)

@@ -100,3 +100,39 @@ def test_config5_rank_slab_of_one_billion(psa, torch_mod):
         total += st.pairs()
         total_tests += st.tests()
     assert total == whole and total_tests == tests
+
+
+def test_more_than_four_gigabytes_of_points(psa, torch_mod):
+    """3.7e8 uniform points (4.4 GB of coordinates, 5.8 per cell): the sorted array no longer fits 32-bit byte
+    offsets, which the merged-window kernel's gather lists once assumed.  The default pair test, the merged-window
+    kernel asked for by name, the thread-per-particle kernel and the sum of two slabs must agree, and the count
+    must lie where a uniform density puts it."""
+    torch = torch_mod
+    ht = importlib.import_module("particle_simulation_amd.hosttools")
+    n = 370_000_000
+    assert n * 12 > 2 ** 32
+    xyz = psa.generate_device(ht.UNIFORM, 5, n, 0)
+    st = psa.DeviceStages(n, "cuda:0")
+    st.count_pairs(xyz)
+    st.count_tests()
+    whole, tests = st.pairs(), st.tests()
+    expect = n * (n - 1) / 2 * (4.0 / 3.0 * np.pi * 0.05 ** 3) / 8000.0
+    assert abs(whole - expect) < 0.01 * expect                      # 4.5e9 pairs: also beyond 2^32
+    assert int(st.table[NBB ** 3].item()) & 0xFFFFFFFF == n
+    for variant in (5, 0):
+        psa.set_variant("count", variant)
+        st.count_sorted(n)
+        assert st.pairs() == whole, variant
+    psa.set_variant("count", 4)
+    del xyz
+    table = st.table.clone()
+    srt = st.sorted[:n].clone()
+    total = total_tests = 0
+    for a_l, b_l in ((0, 200), (200, 400)):
+        a = int(table[a_l * NBB * NBB].item()) & 0xFFFFFFFF
+        b = n if b_l == 400 else int(table[(b_l + 1) * NBB * NBB].item()) & 0xFFFFFFFF
+        st.count_pairs(srt[a:b].contiguous(), a_l, b_l)
+        st.count_tests(a_l, b_l)
+        total += st.pairs()
+        total_tests += st.tests()
+    assert total == whole and total_tests == tests
