@@ -343,10 +343,14 @@ def main():
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic_%s.json" % args.workload)))
             if files:
                 with open(files[-1]) as f:
-                    tk = json.load(f).get("kernels", {}).get(dom)
-                if tk:
+                    prof_file = json.load(f)
+                tk = prof_file.get("kernels", {}).get(dom)
+                dk["traffic_source"] = os.path.relpath(files[-1], ROOT)
+                # measured on these very kernels?  (a profile of older device sources says nothing about this build)
+                if prof_file.get("device_source_hash") != ht.device_source_hash():
+                    dk["traffic_stale"] = "device sources changed since %s was measured" % dk["traffic_source"]
+                elif tk:
                     traffic = tk["hbm_bytes"] / 1e9
-                    dk["traffic_source"] = os.path.relpath(files[-1], ROOT)
         # The dominant kernel against the roofline that bounds it.  A pair-test kernel is priced both ways --
         # 9 unfused binary32 operations per reference test against the vector peak without FMA credit, and its
         # compulsory bytes (12 N + 4 C) against HBM -- and the larger fraction names the bound.

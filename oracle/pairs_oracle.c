@@ -113,7 +113,7 @@ uint32_t orc_parse_float_bits(const char *tok, const char **endp, int *err)
     int sh = 40 - s;
     uint32_t mant = (sh >= 0 && sh < 64) ? (uint32_t)(m >> sh) : 0u;
     static const int exp_of_digit[10] = {0, 0, 1, 1, 2, 2, 2, 2, 3, 3};
-    e2 += exp_of_digit[first];
+    e2 += exp_of_digit[first > 9 ? 9 : first];   /* (a byte above '9' in the scan: the reference reads its table out of range) */
     /* parse.h:135-140 */
     return ((uint32_t)neg << 31) | ((uint32_t)((e2 + 127) & 0xFF) << 23) | (mant & 0x7FFFFFu);
 }

@@ -1,6 +1,6 @@
 """Build driver: compiles the HIP library and the C host tools in-tree.
 
-    python particle-simulation_amd/build.py [--force]
+    python particle-simulation_amd/build.py [--force] [--sanitize]
 
 Outputs (all git-ignored, all shipped to the GPU box with the tree):
     particle-simulation_amd/libpaircount.so   HIP kernels + C ABI (include/paircount.h)
@@ -117,6 +117,14 @@ def build_oracle(force=False):
     return os.path.join(odir, "liboracle.so")
 
 
+def build_sanitizer_flavours(force=False):
+    """The host code under AddressSanitizer+UndefinedBehaviorSanitizer and under ThreadSanitizer (CPU only, test
+    infrastructure: oracle/Makefile target `san`; the reference's counterpart is `make debug`, Makefile:12-17)."""
+    odir = os.path.join(ROOT, "oracle")
+    _run(["make", "-C", odir, "san"] + (["-B"] if force else []))
+    return [os.path.join(odir, "_san", n) for n in ("main_asan", "main_tsan", "xyzhost_asan", "xyzhost_tsan")]
+
+
 def build_all(force=False):
     lib = build_hip(force)
     host = build_host(force)
@@ -125,5 +133,5 @@ def build_all(force=False):
 
 
 if __name__ == "__main__":
-    for p in build_all("--force" in sys.argv):
+    for p in build_all("--force" in sys.argv) + (build_sanitizer_flavours("--force" in sys.argv) if "--sanitize" in sys.argv else []):
         print("built", os.path.relpath(p, ROOT))

@@ -85,7 +85,9 @@ static inline uint32_t xyz_parse_float_bits(const char *tok, const char **end, i
     const int sh = 40 - __builtin_clzll(m);
     const uint32_t mant = (sh >= 0) ? (uint32_t)(m >> sh) : 0u;
     static const int8_t log2_digit[10] = {0, 0, 1, 1, 2, 2, 2, 2, 3, 3};
-    e2 += log2_digit[lead];
+    /* (a byte above '9' inside the scanned characters -- malformed text -- makes the reference read its table,
+       parse.h:132, out of range; here, as in the device tokenizer, it counts as a 9) */
+    e2 += log2_digit[lead > 9 ? 9 : lead];
     return ((uint32_t)neg << 31) | ((uint32_t)((e2 + 127) & 0xFF) << 23) | (mant & 0x7FFFFFu);
 }
 

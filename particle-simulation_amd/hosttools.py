@@ -144,3 +144,20 @@ def filter_slab(xyz, x_lo, x_hi):
     out = np.empty_like(xyz)
     n = lib().xyz_filter_slab(xyz.ctypes.data, xyz.shape[0], x_lo, x_hi, out.ctypes.data)
     return out[:n].copy()
+
+
+def device_source_hash():
+    """First 16 hex digits of the SHA-256 over the device sources (csrc/*, include/paircount.h, in name order):
+    what a measurement of the kernels was taken on.  bench.py compares it with the hash stored in a committed
+    traffic profile and drops the figure when the kernels have changed since."""
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha256()
+    csrc = os.path.join(here, "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".h", ".hip")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    with open(os.path.join(os.path.dirname(here), "include", "paircount.h"), "rb") as f:
+        h.update(b"paircount.h\0" + f.read())
+    return h.hexdigest()[:16]

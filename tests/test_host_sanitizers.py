@@ -1,0 +1,91 @@
+"""CPU: the product's host code under AddressSanitizer + UndefinedBehaviorSanitizer and under ThreadSanitizer
+(the counterpart of the reference's `make debug`, Makefile:12-17).  oracle/Makefile's target `san` links the C
+host program against a CPU stand-in for the GPU library (oracle/paircount_stub.c: the streaming interface on
+top of the oracle) and wraps the host tools library in a driver; both flavours must print the golden counts
+through every routing mode of the host program -- one slab, -g N, explicit cuts, the slab queue, binary input,
+blocks handed over as text -- with a clean exit status and no sanitizer report."""
+import importlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAN = os.path.join(ROOT, "oracle", "_san")
+FLAVOURS = ("asan", "tsan")
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1",
+           TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def sanitizer_builds():
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "san"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def _main(flavour, args, extra_env=None, timeout=300):
+    r = subprocess.run([os.path.join(SAN, "main_" + flavour)] + args, capture_output=True, text=True, timeout=timeout,
+                       env=dict(ENV, **(extra_env or {})))
+    assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    return r
+
+
+MODES = [
+    (["-p", "1"], {}),
+    (["-p", "5", "-c", "3"], {}),
+    (["-p", "5", "-g", "2"], {"PAIRCOUNT_DEVICES": "0,0"}),
+    (["-p", "4", "-g", "3"], {"PAIRCOUNT_DEVICES": "0,0,0", "PAIRCOUNT_CUTS": "0,199,201,400"}),
+    (["-p", "7", "-g", "8"], {"PAIRCOUNT_DEVICES": "0,0,0,0,0,0,0,0"}),
+    (["-p", "5", "-g", "2"], {"PAIRCOUNT_DEVICES": "0,0", "PAIRCOUNT_QUEUE": "7"}),
+    (["-p", "3", "-g", "3"], {"PAIRCOUNT_DEVICES": "0,0,0", "PAIRCOUNT_QUEUE": "64"}),
+    (["-p", "4"], {"PAIRCOUNT_GPU_TOKENIZER": "2"}),
+]
+
+
+@pytest.mark.parametrize("flavour", FLAVOURS)
+def test_host_program_under_sanitizers_prints_the_golden_counts(flavour, golden_dir, tmp_path):
+    with open(os.path.join(golden_dir, "counts.json")) as f:
+        counts = json.load(f)
+    for name, info in counts.items():
+        path = os.path.join(golden_dir, name)
+        binp = str(tmp_path / name.replace(".xyz", ".f32"))
+        np.load(os.path.join(golden_dir, name.replace(".xyz", ".f32.npy"))).astype(np.float32).tofile(binp)
+        for args, env in MODES:
+            for f in (path, binp):
+                if f == binp and "PAIRCOUNT_GPU_TOKENIZER" in env:
+                    continue
+                r = _main(flavour, ["-f", f] + args, env)
+                assert r.returncode == 0, (name, args, env, r.stderr[-2000:])
+                assert r.stdout == "%d\n" % info["count"], (name, args, env, r.stdout)
+
+
+@pytest.mark.parametrize("flavour", FLAVOURS)
+def test_host_program_under_sanitizers_on_a_larger_clustered_file(flavour, psa, oracle, tmp_path):
+    ht = importlib.import_module("particle_simulation_amd.hosttools")
+    path = str(tmp_path / "b150k.xyz")
+    ht.generate_text(path, ht.BLOBS, 31, 150_000, 300_000)
+    want, tests = oracle.count_pairs(ht.generate(ht.BLOBS, 31, 150_000, 300_000))
+    for args, env in ((["-p", "8"], {"PAIRCOUNT_TIMER": "1"}),
+                      (["-p", "8", "-g", "4"], {"PAIRCOUNT_DEVICES": "0,0,0,0", "PAIRCOUNT_TIMER": "1"}),
+                      (["-p", "6", "-g", "2"], {"PAIRCOUNT_DEVICES": "0,0", "PAIRCOUNT_QUEUE": "5", "PAIRCOUNT_TIMER": "1"})):
+        r = _main(flavour, ["-f", path] + args, env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert int(r.stdout) == want and str(tests) in r.stderr
+    # the reference's failure paths leave through exit(): status 255, nothing on stdout, no report either
+    bad = tmp_path / "bad.xyz"
+    bad.write_text("1.000000 2.000000 3.000000\n12.500000 1.000000 1.000000\n" * 8)
+    r = _main(flavour, ["-f", str(bad), "-p", "3"], {"ASAN_OPTIONS": "detect_leaks=0"})
+    assert r.returncode == 255 and "*str != '.'" in r.stderr and r.stdout == ""
+    r = _main(flavour, ["-f", str(tmp_path / "missing.xyz")])
+    assert r.returncode == 255 and r.stderr.startswith("open:")
+
+
+@pytest.mark.parametrize("flavour", FLAVOURS)
+def test_host_tools_under_sanitizers(flavour, tmp_path):
+    for points, threads in (("60000", "7"), ("1000", "16"), ("5", "3")):
+        r = subprocess.run([os.path.join(SAN, "xyzhost_" + flavour), str(tmp_path / "scratch.xyz"), points, threads],
+                           capture_output=True, text=True, timeout=600, env=ENV)
+        assert r.returncode == 0 and r.stdout == "ok\n", (points, threads, r.stdout, r.stderr[-3000:])
+        assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr

@@ -16,8 +16,19 @@ streaming kernel, whose requests are 128-byte ones, and about right for a gather
 import collections
 import csv
 import glob
+import importlib.util
 import json
+import os
 import sys
+
+
+def device_source_hash():
+    """The hash bench.py checks before it quotes this file (hosttools.device_source_hash)."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "particle-simulation_amd", "hosttools.py")
+    spec = importlib.util.spec_from_file_location("pc_hosttools_for_hash", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.device_source_hash()
 
 NAMES = {"pc_l36_partition<0>": "pc_l3_partition_x", "pc_l36_partition<1>": "pc_l6_partition_y",
          "pc_l7_sort_pencils<768>": "pc_l7_sort_pencils", "pc_l7_sort_pencils<192>": "pc_l7_sort_pencils"}
@@ -35,6 +46,7 @@ def per_kernel(directory):
 def main():
     rd, wr = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
     out = {"workload": sys.argv[4] if len(sys.argv) > 4 else "uniform100m",
+           "device_source_hash": device_source_hash(),
            "method": "rocprofv3 --pmc, one pass for the read request counters (TCC_EA0_RDREQ, _32B, _64B, _128B) and one "
                      "for the write request counters (TCC_EA0_WRREQ, _64B); bytes = sum of request sizes; averages per "
                      "launch over the launches a pass saw (the dispatches of 'pc_c3_count_groups' are two gated launches "
