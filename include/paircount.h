@@ -129,6 +129,24 @@ int pc_parse_text_device(const char *d_text, uint64_t bytes, float *d_xyz, uint6
                          uint64_t *d_npoints, int32_t *d_status, void *d_workspace,
                          size_t workspace_bytes, void *stream);
 
+/* Multi-GPU runs without per-point routing on the host.  The parser threads append
+   whole, unrouted blocks to an "arrival" context on any GPU; pc_export_layers then
+   closes that context for appends, groups its points by x layer ON ITS DEVICE (the
+   first level of the binning) and returns the device array and, in
+   layer_start[0 .. PC_NBB] (404 entries, host memory), the first point of every
+   layer: layer l is points [layer_start[l], layer_start[l+1]).  The array belongs
+   to the context and lives until pc_destroy.  The owner of an x slab [lo, hi) takes
+   layers lo .. hi (its halo layer included: every neighbour offset at main.c:195-209
+   has di in {0,+1}) from every arrival context with one pc_import_device each -- a
+   peer copy from device `src_device` (a plain device copy when it is the context's
+   own) into a context that pc_set_slab has restricted to the slab -- and pc_finish
+   counts it.  Both calls block until done; thread-safe like pc_append.
+   PC_ERR_DOMAIN from pc_export_layers if a coordinate lies outside the grid.
+   No counterpart in the reference (one process, one address space): this is the
+   "insert" of main.c:132-138 for points that already sit on another GPU. */
+int pc_export_layers(pc_context *ctx, const float **d_points, uint32_t *layer_start);
+int pc_import_device(pc_context *ctx, int src_device, const float *d_xyz, uint64_t n);
+
 /* Replaces flatten(hm,&keys,&size) + count(hm,keys,len) (hashmap.h:34,137;
    main.c:236,331-335): bins every appended point and counts the pairs.
    Called once, from one thread, after all appends returned.  *npairs is the

@@ -69,6 +69,8 @@ struct pc_context {
     uint64_t size, cap;
     int x_lo, x_hi, finished;
     int64_t npairs, tests;
+    float *by_layer;                 /* pc_export_layers: the points grouped by x layer */
+    uint32_t layer_start[PC_NBB + 1];
 };
 
 static __thread char g_err[256];
@@ -139,6 +141,38 @@ int pc_append_text(pc_context *c, const char *text, uint64_t bytes, uint64_t *n_
     return rc;
 }
 
+/* the points grouped by x layer (a counting sort on the reference's cell index, main.c:134) */
+int pc_export_layers(pc_context *c, const float **d_points, uint32_t *layer_start)
+{
+    if (!c || !d_points || !layer_start) return fail(PC_ERR_ARG, "pc_export_layers: null pointer");
+    pthread_mutex_lock(&c->lock);
+    c->finished = 1;
+    if (!c->by_layer) {
+        uint32_t count[PC_NBB + 1] = {0};
+        for (uint64_t p = 0; p < c->size; p++) {
+            const int l = orc_cell_index(c->xyz[3 * p]);
+            if (l < 0 || l >= PC_NLAYERS) { pthread_mutex_unlock(&c->lock); return fail(PC_ERR_DOMAIN, "a coordinate lies outside the reference's domain (-10,10)"); }
+            count[l]++;
+        }
+        uint32_t run = 0, cursor[PC_NBB + 1];
+        for (int l = 0; l <= PC_NBB; l++) { c->layer_start[l] = cursor[l] = run; run += count[l]; }
+        c->by_layer = (float *)malloc((c->size ? c->size : 1) * 12);
+        if (!c->by_layer) { pthread_mutex_unlock(&c->lock); return fail(PC_ERR_NOMEM, "pc_export_layers: out of memory"); }
+        for (uint64_t p = 0; p < c->size; p++)
+            memcpy(c->by_layer + 3 * (size_t)cursor[orc_cell_index(c->xyz[3 * p])]++, c->xyz + 3 * p, 12);
+    }
+    *d_points = c->by_layer;
+    memcpy(layer_start, c->layer_start, sizeof c->layer_start);
+    pthread_mutex_unlock(&c->lock);
+    return PC_OK;
+}
+
+int pc_import_device(pc_context *c, int src_device, const float *d_xyz, uint64_t n)
+{
+    if (src_device < 0) return fail(PC_ERR_ARG, "pc_import_device: bad device");
+    return pc_append(c, d_xyz, n);
+}
+
 int pc_host_alloc(void **p, uint64_t bytes)
 {
     if (!p) return fail(PC_ERR_ARG, "pc_host_alloc: null pointer");
@@ -173,6 +207,7 @@ void pc_destroy(pc_context *c)
 {
     if (!c) return;
     pthread_mutex_destroy(&c->lock);
+    free(c->by_layer);
     free(c->xyz);
     free(c);
 }

@@ -44,6 +44,8 @@ ABI = [
     ("pc_append_text", _i32, [_vp, _c.c_char_p, _u64, _c.POINTER(_u64)]),
     ("pc_parse_workspace_bytes", _sz, [_u64]),
     ("pc_parse_text_device", _i32, [_vp, _u64, _vp, _u64, _vp, _vp, _vp, _sz, _vp]),
+    ("pc_export_layers", _i32, [_vp, _c.POINTER(_vp), _c.POINTER(_c.c_uint32)]),
+    ("pc_import_device", _i32, [_vp, _i32, _vp, _u64]),
     ("pc_finish", _i32, [_vp, _c.POINTER(_c.c_int64)]),
     ("pc_tests", _i32, [_vp, _c.POINTER(_c.c_int64)]),
     ("pc_size", _i32, [_vp, _c.POINTER(_u64)]),
@@ -97,6 +99,12 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise PairCountError(-2, "HIP library %s is missing; run __graft_entry__.build()" % LIB_PATH)
+        # One HIP runtime per process: PyTorch ships its own libamdhip64 and, loaded second, finds the GPUs taken
+        # ("No HIP GPUs are available").  Loaded first, its copy also satisfies this library's dependency.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = ctypes.CDLL(LIB_PATH)
         for name, restype, argtypes in ABI:
             fn = getattr(handle, name)      # AttributeError if a declared symbol is not exported
@@ -196,6 +204,19 @@ class PairCounter:
         n = ctypes.c_uint64()
         _check(lib().pc_append_text(self._h, data, len(data), ctypes.byref(n)))
         return n.value
+
+    def export_layers(self):
+        """Groups the context's points by x layer on its device.  Returns (device address of the array,
+        numpy array of 404 layer starts); see pc_export_layers."""
+        import numpy as np
+        ptr = ctypes.c_void_p()
+        starts = (ctypes.c_uint32 * (PC_NBB + 1))()
+        _check(lib().pc_export_layers(self._h, ctypes.byref(ptr), starts))
+        return ptr.value, np.frombuffer(starts, dtype=np.uint32).astype(np.int64)
+
+    def import_device(self, src_device, address, n):
+        """n points at a device address of GPU `src_device` (e.g. a layer range of export_layers) into this context."""
+        _check(lib().pc_import_device(self._h, int(src_device), ctypes.c_void_p(int(address)), int(n)))
 
     def size(self):
         n = ctypes.c_uint64()

@@ -885,6 +885,11 @@ struct pc_context {
     char finish_msg[256], append_msg[256];
     int64_t npairs, ntests;
     float ms[2];
+    // pc_export_layers: the points grouped by x layer (inside export_ws, which also holds the kernels' counters)
+    void *export_ws;
+    const float *export_points;
+    int exported;
+    uint32_t export_start[PC_L_BINS];
 };
 
 extern "C" int pc_create(pc_context **out, int device, uint64_t expected_points)
@@ -1213,6 +1218,79 @@ extern "C" int pc_append_text(pc_context *c, const char *text, uint64_t bytes, u
     return PC_OK;
 }
 
+// ------------------------------------------------------- routing on the devices --
+// Level X of the binning as a service: the context's points grouped by x layer, so that a multi-GPU host hands
+// each slab owner its layers as ONE contiguous range per source context (a peer copy) instead of routing point
+// by point on the host.  The order inside a layer is unspecified.
+extern "C" int pc_export_layers(pc_context *c, const float **d_points, uint32_t *layer_start)
+{
+    if (!c || !d_points || !layer_start) return pc_fail(PC_ERR_ARG, "pc_export_layers: null pointer");
+    *d_points = nullptr;
+    pthread_rwlock_wrlock(&c->lock);            // waits for copies in flight
+    struct unlock_on_exit {
+        pthread_rwlock_t *l;
+        ~unlock_on_exit() { pthread_rwlock_unlock(l); }
+    } guard{&c->lock};
+    if (c->append_rc) return pc_fail(c->append_rc, "an earlier append failed (%s): the context holds no usable point set", c->append_msg);
+    c->finished = 1;                             // closed for appends: the exported ranges stay what they are
+    if (!c->exported) {
+        PC_HIP(hipSetDevice(c->device));
+        geo_scope scope(c->geo);
+        const uint64_t n = c->size;
+        if (!c->export_ws && hipMalloc(&c->export_ws, pc_workspace_bytes(n)) != hipSuccess)
+            return pc_fail(PC_ERR_NOMEM, "pc_export_layers: device allocation failed for %llu points", (unsigned long long)n);
+        const pc_lds_ws w = carve_lds_ws(c->export_ws, n);
+        hipStream_t s = nullptr;
+        const bool counted = c->layers_counted != 0;
+        PC_HIP(hipMemsetAsync(w.layer_count, 0, (PC_L_NREP * PC_L_BINS + PC_L_NREP * PC_L_PSTRIDE + 8) * sizeof(uint32_t), s));
+        if (counted)
+            PC_HIP(hipMemcpyAsync(w.layer_count, c->d_layer_count, PC_L_NREP * PC_L_BINS * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        else {
+            PC_HIP(hipMemsetAsync(c->d_status, 0, 4, s));
+            if (n) PC_LAUNCH("pc_l1_hist_x", pc_l1_hist_x, dim3(grid_for(n, PC_L_TILE, 2048)), dim3(PC_L_TPB), s, c->d_xyz, n,
+                             w.layer_count, c->d_status, t_geo);
+        }
+        PC_LAUNCH("pc_l2_scan_x", pc_l2_scan_x, dim3(1), dim3(512), s, w.layer_count, w.layer_start, w.layer_cursor,
+                  w.layer_tile, w.tile_layer, w.big_count + 3, 0u);
+        if (n) PC_LAUNCH("pc_l3_partition_x", pc_l36_partition<0>, dim3((unsigned)((n + PC_L_TILE - 1) / PC_L_TILE)), dim3(PC_L_XTPB), s,
+                         c->d_xyz, n, w.tmp, w.layer_start, w.layer_tile, w.tile_layer, w.layer_cursor, w.ycell, t_geo);
+        PC_HIP(hipGetLastError());
+        int32_t host_status = 0;
+        PC_HIP(hipMemcpyAsync(c->export_start, w.layer_start, PC_L_BINS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        PC_HIP(hipMemcpyAsync(&host_status, c->d_status, 4, hipMemcpyDeviceToHost, s));
+        PC_HIP(hipStreamSynchronize(s));
+        if (host_status & 1) return pc_fail(PC_ERR_DOMAIN, "a coordinate lies outside the reference's domain (-10,10)");
+        c->export_points = w.tmp;
+        c->exported = 1;
+    }
+    *d_points = c->export_points;
+    memcpy(layer_start, c->export_start, PC_L_BINS * sizeof(uint32_t));
+    return PC_OK;
+}
+
+extern "C" int pc_import_device(pc_context *c, int src_device, const float *d_xyz, uint64_t n)
+{
+    if (!c) return pc_fail(PC_ERR_ARG, "pc_import_device: null context");
+    if (n == 0) return PC_OK;
+    if (!d_xyz) return pc_fail(PC_ERR_ARG, "pc_import_device: null points");
+    int ndev = 0;
+    PC_HIP(hipGetDeviceCount(&ndev));
+    if (src_device < 0 || src_device >= ndev) return pc_fail(PC_ERR_ARG, "pc_import_device: device %d not in [0,%d)", src_device, ndev);
+    PC_HIP(hipSetDevice(c->device));
+    uint64_t off;
+    int rc = reserve_slots(c, n, &off);         // returns with the read lock held
+    if (rc) return rc;
+    hipStream_t s = nullptr;
+    hipError_t e = src_device == c->device
+                       ? hipMemcpyAsync(c->d_xyz + 3 * off, d_xyz, n * 12, hipMemcpyDeviceToDevice, s)
+                       : hipMemcpyPeerAsync(c->d_xyz + 3 * off, c->device, d_xyz, src_device, n * 12, s);
+    if (e == hipSuccess) count_layers_of(c, off, n, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    pthread_rwlock_unlock(&c->lock);
+    if (e != hipSuccess) return append_failed(c, "pc_import_device: copy: %s", hipGetErrorString(e));
+    return PC_OK;
+}
+
 extern "C" int pc_size(pc_context *c, uint64_t *n)
 {
     if (!c || !n) return pc_fail(PC_ERR_ARG, "pc_size: null pointer");
@@ -1374,6 +1452,7 @@ extern "C" void pc_destroy(pc_context *c)
         if (c->d_xyz) (void)hipFree(c->d_xyz);
         if (c->d_layer_count) (void)hipFree(c->d_layer_count);
         if (c->d_status) (void)hipFree(c->d_status);
+        if (c->export_ws) (void)hipFree(c->export_ws);
         for (int i = 0; i < c->n_stages; i++) text_stage_free(c->stages[i]);
     }
     pthread_rwlock_destroy(&c->lock);

@@ -23,6 +23,12 @@
  * (every neighbour offset of the reference has dx in {0,+1}, main.c:195-209) -- the
  * slabs are finished concurrently and their counts added: the fold of the
  * counter threads' totals at main.c:231.  Without -g nothing changes.
+ * By default the routing itself happens on the GPUs: parser thread t appends whole,
+ * unrouted blocks to an arrival context on GPU t mod NUM, each arrival context groups
+ * its points by x layer (pc_export_layers), and every slab owner pulls its layers and
+ * its halo layer from every arrival context with one peer copy each
+ * (pc_import_device).  PAIRCOUNT_ROUTE=host keeps the routing in the parser threads,
+ * point by point.
  * PAIRCOUNT_QUEUE=K (K >= 2, with or without -g) cuts the x range into K slabs that
  * are not tied to a GPU: the parser threads keep each slab's points in host memory,
  * and afterwards one thread per GPU takes the next slab from a shared counter -- most
@@ -98,6 +104,7 @@ typedef struct {
     uint32_t block_points;           /* capacity of one (thread, slab) block */
     int queued;                      /* slabs wait in host memory for the next free GPU */
     int gpus;                        /* queued: GPUs (taker threads), device[g] of taker g */
+    int device_routing;              /* ctx[] are arrival contexts: the slabs are cut on the GPUs afterwards */
 } slab_set;
 
 typedef struct {
@@ -111,6 +118,7 @@ typedef struct {
     uint32_t fill[MAX_SLABS];
     chunk *held[MAX_SLABS];  /* queued slabs: this thread's chunks, newest first */
     uint64_t held_points[MAX_SLABS];
+    int home;                /* the context this thread appends whole blocks to (0 unless the GPUs do the routing) */
     int binary;              /* the file holds float triples, not text */
     int gpu_text;            /* the GPU tokenizes: this thread only cuts its range into blocks of whole lines */
     char msg[256];
@@ -188,10 +196,10 @@ static void append_binary_share(worker *w)
     const uint64_t total = w->size / 12;
     const uint64_t first = total * (uint64_t)w->t / (uint64_t)w->nt, last = total * (uint64_t)(w->t + 1) / (uint64_t)w->nt;
     const float *pts = (const float *)w->file;
-    if (w->slabs->n == 1 && !w->slabs->queued) {
+    if ((w->slabs->n == 1 || w->slabs->device_routing) && !w->slabs->queued) {
         for (uint64_t i = first; i < last; i += 16 * BLOCK_POINTS) {
             const uint64_t m = last - i < 16 * BLOCK_POINTS ? last - i : 16 * BLOCK_POINTS;
-            if (append_block(w, 0, pts + 3 * i, m) != PC_OK) return;
+            if (append_block(w, w->home, pts + 3 * i, m) != PC_OK) return;
         }
         return;
     }
@@ -214,11 +222,11 @@ static void tokenize_range(worker *w, const char *p, const char *stop)
             return;
         }
         if (++n == BLOCK_POINTS) {
-            if (append_block(w, 0, block, n) != PC_OK) return;
+            if (append_block(w, w->home, block, n) != PC_OK) return;
             n = 0;
         }
     }
-    if (n) append_block(w, 0, block, n);
+    if (n) append_block(w, w->home, block, n);
 }
 
 /* PAIRCOUNT_GPU_TOKENIZER=K: the file is cut into blocks of whole lines (the reference's thread split, main.c:109-129,
@@ -281,7 +289,7 @@ static void *parser_thread(void *arg)
     if (w->gpu_text) { share_text_blocks(w); return NULL; }
     const char *p, *stop;
     xyz_thread_range(w->file, w->size, w->t, w->nt, &p, &stop);
-    if (w->slabs->n > 1) {
+    if (w->slabs->n > 1 && !w->slabs->device_routing) {
         while (p < stop) {
             int err = 0;
             float pt[3];
@@ -329,6 +337,53 @@ static void *finish_thread(void *arg)
     if (f->rc != PC_OK) { snprintf(f->msg, sizeof f->msg, "%s", pc_last_error()); return NULL; }
     pc_phase_ms(f->ctx, f->ms);
     pc_tests(f->ctx, &f->tests);
+    return NULL;
+}
+
+/* Routing on the GPUs, step 1: an arrival context groups its points by x layer. */
+typedef struct {
+    pc_context *ctx;
+    int device, rc;
+    const float *points;                 /* device array, layer l = points [start[l], start[l+1]) */
+    uint32_t start[PC_NBB + 1];
+    char msg[256];
+} exporter;
+
+static void *export_thread(void *arg)
+{
+    exporter *e = (exporter *)arg;
+    e->rc = pc_export_layers(e->ctx, &e->points, e->start);
+    if (e->rc != PC_OK) snprintf(e->msg, sizeof e->msg, "%s", pc_last_error());
+    return NULL;
+}
+
+/* Step 2: the owner of slab o pulls layers cut[o] .. cut[o+1] (its halo layer included; the last slab ends at
+   layer 399) out of every arrival context -- one copy per source -- and counts. */
+typedef struct {
+    const slab_set *slabs;
+    const exporter *sources;
+    int o;
+    finisher *fin;
+    pc_context *ctx;
+} owner;
+
+static void *owner_thread(void *arg)
+{
+    owner *w = (owner *)arg;
+    const slab_set *S = w->slabs;
+    finisher *f = w->fin;
+    const int lo = S->cut[w->o], hi = w->o == S->n - 1 ? LAYERS : S->cut[w->o + 1] + 1;      /* layers [lo, hi) */
+    uint64_t total = 0;
+    for (int s = 0; s < S->n; s++) total += w->sources[s].start[hi] - w->sources[s].start[lo];
+    f->rc = pc_create(&w->ctx, S->device[w->o], total + 1);
+    if (f->rc == PC_OK) f->rc = pc_set_slab(w->ctx, S->cut[w->o], S->cut[w->o + 1]);
+    for (int s = 0; s < S->n && f->rc == PC_OK; s++) {
+        const exporter *e = &w->sources[s];
+        f->rc = pc_import_device(w->ctx, e->device, e->points + 3 * (size_t)e->start[lo], e->start[hi] - e->start[lo]);
+    }
+    if (f->rc != PC_OK) { snprintf(f->msg, sizeof f->msg, "%s", pc_last_error()); return NULL; }
+    f->ctx = w->ctx;
+    finish_thread(f);
     return NULL;
 }
 
@@ -508,11 +563,14 @@ int main(int argc, char **argv)
        blocks 8 slabs took 0.45 s for 100 M points and 4.1 s for 1 G, with 65 536-point blocks 0.24 s and 1.6 s */
     S.block_points = S.n <= 16 ? BLOCK_POINTS : (BLOCK_POINTS * 16 / (uint32_t)S.n < 4096 ? 4096 : BLOCK_POINTS * 16 / (uint32_t)S.n);
     const uint64_t expect = binary ? size / 12 + 1 : size / 24 + 1024;
+    S.device_routing = S.n > 1 && !S.queued && !(getenv("PAIRCOUNT_ROUTE") && strcmp(getenv("PAIRCOUNT_ROUTE"), "host") == 0);
     for (int s = 0; s < S.n && !S.queued; s++) {
-        /* capacity hint: the slab's share of the points, with room for its halo layer and some imbalance */
-        const uint64_t hint = S.n == 1 ? expect : expect * (uint64_t)(S.cut[s + 1] - S.cut[s] + 2) / LAYERS + 4096;
+        /* capacity hint: the slab's share of the points, with room for its halo layer and some imbalance -- or,
+           when the GPUs do the routing, an arrival context's share of the parser threads' output */
+        const uint64_t hint = S.n == 1 ? expect : S.device_routing ? expect / (uint64_t)S.n + expect / 16 + 4096
+                                       : expect * (uint64_t)(S.cut[s + 1] - S.cut[s] + 2) / LAYERS + 4096;
         if (pc_create(&S.ctx[s], S.device[s], hint) != PC_OK ||
-            (S.n > 1 && pc_set_slab(S.ctx[s], S.cut[s], S.cut[s + 1]) != PC_OK)) {
+            (S.n > 1 && !S.device_routing && pc_set_slab(S.ctx[s], S.cut[s], S.cut[s + 1]) != PC_OK)) {
             fprintf(stderr, "pc_create: %s\n", pc_last_error());
             return -1;
         }
@@ -541,7 +599,8 @@ int main(int argc, char **argv)
         g_text_blocks = (size + TEXT_BLOCK_BYTES - 1) / TEXT_BLOCK_BYTES;
         if (g_text_blocks > 0x7FFFFFFF) g_text_blocks = 0x7FFFFFFF;
     }
-    const size_t thread_floats = gpu_text ? (TEXT_BLOCK_BYTES + TEXT_LINE_MAX) / 4 : (size_t)S.n * S.block_points * 3;
+    const size_t thread_floats = gpu_text ? (TEXT_BLOCK_BYTES + TEXT_LINE_MAX) / 4
+                                          : S.device_routing ? (size_t)BLOCK_POINTS * 3 : (size_t)S.n * S.block_points * 3;
     if (size && !S.queued && pc_host_alloc((void **)&pinned, (uint64_t)pthreads * thread_floats * 4) != PC_OK) {
         fprintf(stderr, "pc_host_alloc: %s\n", pc_last_error());
         return -1;
@@ -549,7 +608,7 @@ int main(int argc, char **argv)
     for (int t = 0; t < pthreads; t++) {
         w[t] = (worker){.file = file, .size = size, .t = t, .nt = pthreads, .slabs = &S, .status = 0,
                         .block = pinned + (size_t)t * thread_floats, .binary = binary,
-                        .gpu_text = gpu_text};
+                        .gpu_text = gpu_text, .home = S.device_routing ? t % S.n : 0};
         if (size == 0) continue;
         if (pthread_create(&th[t], NULL, parser_thread, &w[t]) != 0) { perror("pthread_create"); exit(-1); }
     }
@@ -597,7 +656,26 @@ int main(int argc, char **argv)
         for (int g = 0; g < S.gpus; g++)
             if (pthread_join(fth[g], NULL) != 0) { perror("pthread_join"); exit(-1); }
     }
-    for (int s = 0; s < S.n && !S.queued; s++) {
+    static exporter ex[MAX_SLABS];
+    static owner own[MAX_SLABS];
+    if (S.device_routing) {
+        /* every arrival context groups its points by x layer, concurrently; then the slab owners pull and count */
+        double t1 = now_us();
+        for (int s = 0; s < S.n; s++) {
+            ex[s] = (exporter){.ctx = S.ctx[s], .device = S.device[s]};
+            if (pthread_create(&fth[s], NULL, export_thread, &ex[s]) != 0) { perror("pthread_create"); exit(-1); }
+        }
+        for (int s = 0; s < S.n; s++)
+            if (pthread_join(fth[s], NULL) != 0) { perror("pthread_join"); exit(-1); }
+        for (int s = 0; s < S.n; s++)
+            if (ex[s].rc != PC_OK) { fprintf(stderr, "pc_finish: %s\n", ex[s].msg); return -1; }
+        if (timer) fprintf(stderr, "%16s:  %10.0f us\n", "export(wall)", now_us() - t1);
+        for (int s = 0; s < S.n; s++) {
+            own[s] = (owner){.slabs = &S, .sources = ex, .o = s, .fin = &fin[s]};
+            if (pthread_create(&fth[s], NULL, owner_thread, &own[s]) != 0) { perror("pthread_create"); exit(-1); }
+        }
+    }
+    for (int s = 0; s < S.n && !S.queued && !S.device_routing; s++) {
         fin[s].ctx = S.ctx[s];
         if (S.n == 1) finish_thread(&fin[s]);
         else if (pthread_create(&fth[s], NULL, finish_thread, &fin[s]) != 0) { perror("pthread_create"); exit(-1); }
@@ -606,6 +684,11 @@ int main(int argc, char **argv)
     float ms[2] = {0, 0};
     for (int s = 0; s < S.n && S.n > 1 && !S.queued; s++)   /* all of them, before any result is judged: no thread may */
         if (pthread_join(fth[s], NULL) != 0) { perror("pthread_join"); exit(-1); }   /* still be inside HIP at exit */
+    if (S.device_routing)
+        for (int s = 0; s < S.n; s++) {                 /* the arrival contexts are done with; the owners' take their place */
+            pc_destroy(S.ctx[s]);
+            S.ctx[s] = own[s].ctx;
+        }
     for (int s = 0; s < S.n; s++) {
         if (fin[s].rc != PC_OK) {
             fprintf(stderr, "pc_finish: %s\n", fin[s].msg);
@@ -623,7 +706,7 @@ int main(int argc, char **argv)
         fprintf(stderr, "%16s:  %10ld\n", "tests", (long)tests);
         for (int s = 0; s < S.n && S.n > 1; s++) {
             uint64_t in_slab = held[s];
-            if (!S.queued) pc_size(S.ctx[s], &in_slab);
+            if (!S.queued && S.ctx[s]) pc_size(S.ctx[s], &in_slab);
             fprintf(stderr, "   slab %2d gpu %2d layers [%3d,%3d): %10lu points, binning %8.0f us, count %8.0f us\n", s,
                     S.device[S.queued ? taken_by[s] : s], S.cut[s], S.cut[s + 1], (unsigned long)in_slab,
                     fin[s].ms[0] * 1e3, fin[s].ms[1] * 1e3);
@@ -632,6 +715,6 @@ int main(int argc, char **argv)
             fprintf(stderr, "   taker %2d gpu %2d: busy %10.0f us (create %.0f, append %.0f, finish %.0f, destroy %.0f)\n", g,
                     S.device[g], busy_us[g], tk[g].part_us[0], tk[g].part_us[1], tk[g].part_us[2], tk[g].part_us[3]);
     }
-    for (int s = 0; s < S.n && !S.queued; s++) pc_destroy(S.ctx[s]);
+    for (int s = 0; s < S.n && !S.queued; s++) pc_destroy(S.ctx[s]);      /* (pc_destroy(NULL) is a no-op) */
     return 0;
 }

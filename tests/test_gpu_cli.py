@@ -109,7 +109,8 @@ def test_main_multi_gpu_slabs(ht, oracle, golden_dir, tmp_path):
     with open(os.path.join(golden_dir, "counts.json")) as f:
         counts = json.load(f)
     for name, info in counts.items():
-        for g, extra in (("2", {}), ("3", {"PAIRCOUNT_CUTS": "0,199,201,400"}), ("8", {})):
+        for g, extra in (("2", {}), ("3", {"PAIRCOUNT_CUTS": "0,199,201,400"}), ("8", {}),
+                         ("2", {"PAIRCOUNT_ROUTE": "host"}), ("8", {"PAIRCOUNT_ROUTE": "host"})):
             env = dict(os.environ, PAIRCOUNT_DEVICES=",".join("0" * int(g)), **extra)
             r = subprocess.run([ht.MAIN_PATH, "-f", os.path.join(golden_dir, name), "-p", "5", "-g", g],
                                capture_output=True, text=True, timeout=120, env=env)
@@ -122,20 +123,23 @@ def test_main_multi_gpu_slabs(ht, oracle, golden_dir, tmp_path):
     binp = str(tmp_path / "b500k.f32")
     pts.tofile(binp)
     for f in (path, binp):
-        env = dict(os.environ, PAIRCOUNT_GPUS="4", PAIRCOUNT_DEVICES="0,0,0,0", PAIRCOUNT_TIMER="1")
-        r = subprocess.run([ht.MAIN_PATH, "-f", f, "-p", "8"], capture_output=True, text=True, timeout=120, env=env)
-        assert r.returncode == 0, r.stderr
-        assert int(r.stdout) == want and want > 0
-        assert str(tests) in r.stderr and r.stderr.count("slab") == 4
+        for route in ({}, {"PAIRCOUNT_ROUTE": "host"}):          # routed on the GPUs (export / import of layers), or by the parser threads
+            env = dict(os.environ, PAIRCOUNT_GPUS="4", PAIRCOUNT_DEVICES="0,0,0,0", PAIRCOUNT_TIMER="1", **route)
+            r = subprocess.run([ht.MAIN_PATH, "-f", f, "-p", "8"], capture_output=True, text=True, timeout=120, env=env)
+            assert r.returncode == 0, r.stderr
+            assert int(r.stdout) == want and want > 0
+            assert str(tests) in r.stderr and r.stderr.count("slab") == 4
+            assert ("export(wall)" in r.stderr) == (not route)
     # an out-of-domain point (only a binary file can hold one) is still an error, whichever slab it was routed to
     for axis in range(3):
         far = pts[:1000].copy()
         far[500, axis] = 10.5
         fp = str(tmp_path / ("far%d.f32" % axis))
         far.tofile(fp)
-        r = subprocess.run([ht.MAIN_PATH, "-f", fp, "-g", "2"], capture_output=True, text=True, timeout=60,
-                           env=dict(os.environ, PAIRCOUNT_DEVICES="0,0"))
-        assert r.returncode == 255 and "domain" in r.stderr
+        for route in ({}, {"PAIRCOUNT_ROUTE": "host"}):
+            r = subprocess.run([ht.MAIN_PATH, "-f", fp, "-g", "2"], capture_output=True, text=True, timeout=60,
+                               env=dict(os.environ, PAIRCOUNT_DEVICES="0,0", **route))
+            assert r.returncode == 255 and "domain" in r.stderr
 
 
 def test_main_rejects_a_bad_gpu_count(ht, golden_dir):

@@ -38,6 +38,8 @@ MODES = [
     (["-p", "5", "-g", "2"], {"PAIRCOUNT_DEVICES": "0,0"}),
     (["-p", "4", "-g", "3"], {"PAIRCOUNT_DEVICES": "0,0,0", "PAIRCOUNT_CUTS": "0,199,201,400"}),
     (["-p", "7", "-g", "8"], {"PAIRCOUNT_DEVICES": "0,0,0,0,0,0,0,0"}),
+    (["-p", "5", "-g", "2"], {"PAIRCOUNT_DEVICES": "0,0", "PAIRCOUNT_ROUTE": "host"}),
+    (["-p", "7", "-g", "8"], {"PAIRCOUNT_DEVICES": "0,0,0,0,0,0,0,0", "PAIRCOUNT_ROUTE": "host"}),
     (["-p", "5", "-g", "2"], {"PAIRCOUNT_DEVICES": "0,0", "PAIRCOUNT_QUEUE": "7"}),
     (["-p", "3", "-g", "3"], {"PAIRCOUNT_DEVICES": "0,0,0", "PAIRCOUNT_QUEUE": "64"}),
     (["-p", "4"], {"PAIRCOUNT_GPU_TOKENIZER": "2"}),
@@ -69,6 +71,7 @@ def test_host_program_under_sanitizers_on_a_larger_clustered_file(flavour, psa, 
     want, tests = oracle.count_pairs(ht.generate(ht.BLOBS, 31, 150_000, 300_000))
     for args, env in ((["-p", "8"], {"PAIRCOUNT_TIMER": "1"}),
                       (["-p", "8", "-g", "4"], {"PAIRCOUNT_DEVICES": "0,0,0,0", "PAIRCOUNT_TIMER": "1"}),
+                      (["-p", "8", "-g", "3"], {"PAIRCOUNT_DEVICES": "0,0,0", "PAIRCOUNT_TIMER": "1", "PAIRCOUNT_ROUTE": "host"}),
                       (["-p", "6", "-g", "2"], {"PAIRCOUNT_DEVICES": "0,0", "PAIRCOUNT_QUEUE": "5", "PAIRCOUNT_TIMER": "1"})):
         r = _main(flavour, ["-f", path] + args, env, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
