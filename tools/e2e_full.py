@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--slabs", type=int, nargs="*", default=[],
                     help="also time the host program with -g S for each S given, all S slabs on device 0 "
                          "(the multi-GPU path of the host program on a one-GPU box)")
+    ap.add_argument("--routes", nargs="*", default=["device"], choices=["device", "host"],
+                    help="with --slabs: where the points are routed to their slabs (device: layers exported and imported "
+                         "on the GPUs, the default of the host program; host: point by point in the parser threads)")
     ap.add_argument("--sidecar", action="store_true",
                     help="also time the host program on the .f32 form of the same points (no tokenizing)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "e2e_full.json"))
@@ -89,10 +92,10 @@ def main():
             out["gpu_host_program_gpu_tokenizer_%d" % k] = {
                 "wall_s": w, "count": int(r.stdout.strip()),
                 "phases_s": {m.group(1): float(m.group(2)) / 1e6 for m in re.finditer(r"(\w[\w()]*):\s+(\d+) us", r.stderr)}}
-        for k in args.slabs:
+        for k, route in ((k, route) for k in args.slabs for route in args.routes):
             w, r = timed([ht.MAIN_PATH, "-f", path, "-p", str(args.threads), "-g", str(k)],
-                         env=dict(os.environ, PAIRCOUNT_TIMER="1", PAIRCOUNT_DEVICES=",".join(["0"] * k)))
-            out["gpu_host_program_%d_slabs_on_one_gpu" % k] = {
+                         env=dict(os.environ, PAIRCOUNT_TIMER="1", PAIRCOUNT_DEVICES=",".join(["0"] * k), PAIRCOUNT_ROUTE=route))
+            out["gpu_host_program_%d_slabs_on_one_gpu%s" % (k, "" if route == "device" else "_routed_on_host")] = {
                 "wall_s": w, "count": int(r.stdout.strip()),
                 "phases_s": {m.group(1): float(m.group(2)) / 1e6 for m in re.finditer(r"(\w[\w()]*):\s+(\d+) us", r.stderr)},
                 "slabs": [ln.strip() for ln in r.stderr.splitlines() if ln.strip().startswith("slab")]}
