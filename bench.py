@@ -66,6 +66,25 @@ def kernel_bytes(name, n, layers):
     return table.get(name)
 
 
+def measured_valu_ceiling():
+    """What tools/micro/valu_rate.hip measured on an MI355X (committed under profiles/): the chip's rate of plain
+    binary32 vector operations at eight waves per SIMD, and the rate of the pair test's nine-operation distance
+    arithmetic alone (no loads, no bookkeeping).  None if no such profile is in the tree."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*valu_issue_rate.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        rows = json.load(f).get("rows", [])
+    pick = lambda kind: max((r for r in rows if r["kind"] == kind), key=lambda r: r["waves_per_simd"], default=None)
+    mul, test = pick("v_mul_f32"), pick("pair test, 9 plain instructions")
+    if not mul or not test:
+        return None
+    return {"source": os.path.relpath(files[-1], ROOT), "plain_ops_tops": mul["lane_ops_per_s"] / 1e12,
+            "clock_ghz": mul["clock_ghz"], "cycles_per_wave_instruction": mul["ns_per_wave_instruction_per_simd"] * mul["clock_ghz"],
+            "pair_test_arithmetic_tops": 9 * test["tests_per_s"] / 1e12}
+
+
 def spawn_ranks(n, cmd=None, timeout_s=None, grace_s=5.0):
     """The parent of a self-launched multi-rank run: no torch, no HIP, only child processes.
 
@@ -362,6 +381,12 @@ def main():
             roofline["hbm_leg"] = {"achieved_gbs": dk.get("achieved_gbs"), "frac": hbm_frac}
             roofline["valu_leg"] = {"achieved_tops": valu_tops, "peak_tops": VALU_NOFMA_TOPS, "frac": valu_tops / VALU_NOFMA_TOPS,
                                     "ops_per_test": 9}
+            # beside the nominal peak (one wave64 instruction per 2 cycles and SIMD at 2.4 GHz): what the same
+            # chip was measured to issue, and the distance arithmetic of the test by itself
+            ceiling = measured_valu_ceiling()
+            if ceiling:
+                roofline["valu_leg"]["measured"] = dict(ceiling, frac_of_plain_ops=valu_tops / ceiling["plain_ops_tops"],
+                                                        frac_of_pair_test_arithmetic=valu_tops / ceiling["pair_test_arithmetic_tops"])
             if valu_tops / VALU_NOFMA_TOPS > hbm_frac:
                 roofline.update({"bound": "valu", "achieved": valu_tops, "peak": VALU_NOFMA_TOPS, "unit": "TFLOP/s",
                                  "frac": valu_tops / VALU_NOFMA_TOPS})

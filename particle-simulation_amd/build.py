@@ -24,7 +24,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CC = os.environ.get("CC", "gcc")
 
 # -fno-slp-vectorize: the dense pair test's nine plain instructions per 64 tests must not be re-packed into
-# two-wide instructions with register shuffles (packed binary32 arithmetic is no faster per operation on this part)
+# two-wide instructions with register shuffles (a packed binary32 instruction takes two issue slots of a plain
+# one, 4.2 against 2.35 cycles per wave and SIMD: profiles/r3c_valu_issue_rate.txt, tools/micro/valu_rate.hip)
 HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-Wall"] + os.environ.get("PC_EXTRA_FLAGS", "").split()
 # x86-64-v3 (AVX2, BMI2, LZCNT): what the tokenizer's bit tricks compile to single instructions on; the
 # host CPUs of MI355X machines all have it.  (The reference builds with -O3 -march=native.)
