@@ -395,7 +395,11 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
     for (uint32_t e = tid; e < kept; e += TPB) {
         const pc_pt3 p = {buf[3 * e], buf[3 * e + 1], buf[3 * e + 2]};
         const uint32_t b = (uint32_t)pc_cell_index(LEVEL == 0 ? p.x : p.y, geo);
+#ifdef PC_L_EXP_LINEAR                                 // measurement build: the tile goes back where it came from, as one contiguous run
+        const uint32_t slot = (uint32_t)first + e + 0u * delta[b];
+#else
         const uint32_t slot = delta[b] + e;
+#endif
         reinterpret_cast<pc_pt3 *>(dst)[slot] = p;
         if (LEVEL == 0) {
             const int cy = pc_cell_index(p.y, geo);
