@@ -27,8 +27,12 @@
  * unrouted blocks to an arrival context on GPU t mod NUM, each arrival context groups
  * its points by x layer (pc_export_layers), and every slab owner pulls its layers and
  * its halo layer from every arrival context with one peer copy each
- * (pc_import_device).  PAIRCOUNT_ROUTE=host keeps the routing in the parser threads,
- * point by point.
+ * (pc_import_device).  The exact number of points per x layer is known at that moment,
+ * so unless PAIRCOUNT_CUTS names the cuts they are placed where an estimate of the work
+ * -- per layer, 40 units per point for its binning plus the reference's 13.5 n^2 tests per
+ * cell at the layer's mean filling -- balances; for an evenly filled grid these are the
+ * equal widths.  PAIRCOUNT_ROUTE=host keeps the routing in the parser threads, point by
+ * point, with equal widths.
  * PAIRCOUNT_QUEUE=K (K >= 2, with or without -g) cuts the x range into K slabs that
  * are not tied to a GPU: the parser threads keep each slab's points in host memory,
  * and afterwards one thread per GPU takes the next slab from a shared counter -- most
@@ -670,6 +674,25 @@ int main(int argc, char **argv)
         for (int s = 0; s < S.n; s++)
             if (ex[s].rc != PC_OK) { fprintf(stderr, "pc_finish: %s\n", ex[s].msg); return -1; }
         if (timer) fprintf(stderr, "%16s:  %10.0f us\n", "export(wall)", now_us() - t1);
+        if (!getenv("PAIRCOUNT_CUTS")) {
+            /* cuts where the estimated work balances: layer l holds n points, its cells n / 160000 each on
+               average, and a cell with m points costs the reference 13.5 m^2 tests (main.c:210-229: m^2/2 in the
+               cell, 13 m^2 with its neighbours); binning and per-point work count as 40 tests per point */
+            double below[LAYERS + 1];                     /* below[l] = estimated work of layers < l */
+            below[0] = 0;
+            for (int l = 0; l < LAYERS; l++) {
+                double n = 0;
+                for (int s = 0; s < S.n; s++) n += (double)(ex[s].start[l + 1] - ex[s].start[l]);
+                below[l + 1] = below[l] + n * (40.0 + 13.5 * n / ((double)LAYERS * LAYERS));
+            }
+            for (int s = 1, l = 0; s < S.n; s++) {
+                while (l < LAYERS && below[l] * S.n < below[LAYERS] * s) l++;       /* first cut with s/n of the work below it */
+                int c = l;
+                if (c <= S.cut[s - 1]) c = S.cut[s - 1] + 1;                        /* every slab keeps at least one layer */
+                if (c > LAYERS - (S.n - s)) c = LAYERS - (S.n - s);
+                S.cut[s] = c;
+            }
+        }
         for (int s = 0; s < S.n; s++) {
             own[s] = (owner){.slabs = &S, .sources = ex, .o = s, .fin = &fin[s]};
             if (pthread_create(&fth[s], NULL, owner_thread, &own[s]) != 0) { perror("pthread_create"); exit(-1); }
