@@ -281,6 +281,12 @@ int pc_count_pairs_noalloc(const float *d_xyz, uint64_t n, int x_lo, int x_hi,
    unknown name or value. */
 int pc_set_variant(const char *name, int value);
 
+/* The same choice of "bin" or "count" for ONE context: its pc_finish then runs that
+   variant whatever pc_set_variant says at the time (two contexts of a process may
+   differ).  Before pc_finish only.  The remaining names of pc_set_variant size
+   process-wide work areas and stay process-wide. */
+int pc_context_set_variant(pc_context *ctx, const char *name, int value);
+
 /* Per-kernel device timing for the stage functions above: while enabled, a
    pair of HIP events is recorded on the launch stream around each kernel.
    pc_profile_enable(k), k > 1, times only launches 1, k+1, 2k+1, ... of each

@@ -66,6 +66,7 @@ ABI = [
     ("pc_bin_geometry_device", _i32, [_vp, _vp, _u64, _vp, _vp, _vp, _sz, _vp, _vp]),
     ("pc_selfcheck_cell_index_geometry_device", _i32, [_vp, _vp, _vp]),
     ("pc_set_variant", _i32, [_c.c_char_p, _i32]),
+    ("pc_context_set_variant", _i32, [_vp, _c.c_char_p, _i32]),
     ("pc_profile_enable", _i32, [_i32]),
     ("pc_profile_read", _i32, [_c.c_char_p, _sz]),
     ("pc_selfcheck_cell_index_device", _i32, [_vp, _vp]),
@@ -188,6 +189,10 @@ class PairCounter:
             _check(lib().pc_set_slab(self._h, int(slab[0]), int(slab[1])))
         if geometry is not None:
             _check(lib().pc_set_geometry(self._h, ctypes.byref(geometry)))
+
+    def set_variant(self, name, value):
+        """This context's own "bin" / "count" variant (pc_context_set_variant)."""
+        _check(lib().pc_context_set_variant(self._h, name.encode(), int(value)))
 
     def append(self, xyz):
         a, p, n = _host_ptr(xyz)

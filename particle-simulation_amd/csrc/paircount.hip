@@ -131,6 +131,29 @@ static std::atomic<int> g_segments{PC_G_SEG_CAP};  // capacity of the heavy-penc
 static std::atomic<int> g_even{1};                 // 1 = the merged-window kernel's grid is cut down to a whole number of pencils per wave
 static std::atomic<int> g_dense{1};                // who works the segment list off after the merged-window kernel: 1 = the dense kernel (variant 6), 0 = variant 3's
 
+// A context may carry its own choice of the two algorithm variants (pc_context_set_variant); while its pc_finish
+// runs, the calling thread sees that choice instead of the process-wide one (-1: not overridden).
+static thread_local int t_variant_bin = -1, t_variant_count = -1;
+static int variant_bin() { return t_variant_bin >= 0 ? t_variant_bin : g_variant_bin.load(); }
+static int variant_count() { return t_variant_count >= 0 ? t_variant_count : g_variant_count.load(); }
+
+static int check_variant(const char *who, const char *name, int value, int *which)
+{
+    if (!name) return pc_fail(PC_ERR_ARG, "%s: null name", who);
+    if (!strcmp(name, "bin")) {
+        if (value < 0 || value > 1) return pc_fail(PC_ERR_ARG, "%s: bin variant %d unknown", who, value);
+        *which = 0;
+        return PC_OK;
+    }
+    if (!strcmp(name, "count")) {
+        if (value < 0 || value > 7 || value == 6) return pc_fail(PC_ERR_ARG, "%s: count variant %d unknown", who, value);
+        *which = 1;
+        return PC_OK;
+    }
+    *which = -1;
+    return PC_OK;
+}
+
 extern "C" int pc_set_variant(const char *name, int value)
 {
     if (!name) return pc_fail(PC_ERR_ARG, "pc_set_variant: null name");
@@ -507,7 +530,7 @@ static int bin_layers(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
         return pc_fail(PC_ERR_ARG, "pc_bin_device: workspace %zu < %zu bytes", workspace_bytes,
                        pc_workspace_bytes(n));
     hipStream_t s = (hipStream_t)stream;
-    if (g_variant_bin == 1)
+    if (variant_bin() == 1)
         return bin_lds(d_xyz, n, d_sorted_xyz, d_cell_start, d_workspace, d_status, s, layer_lo, layer_hi, layer_counts, home_lo,
                        home_hi, fused);
     const uint64_t m = PC_NCELLS + 2;
@@ -604,7 +627,7 @@ static int count_sorted(const float *d_sorted_xyz, const uint32_t *d_cell_start,
     int rc = check_slab("pc_count_sorted_device", x_lo, x_hi);
     if (rc) return rc;
     if (n == 0 || x_lo == x_hi) return PC_OK;
-    int variant = g_variant_count;
+    int variant = variant_count();
     if (variant == 7) variant = 4;                 // (the fused kernel is part of the whole-path entry points; this is their other route)
     if (variant == 4) {
         // Sparse inputs: a window of cells holds too few particles to pay for its bookkeeping, and the
@@ -707,7 +730,7 @@ extern "C" int pc_count_sorted_device(const float *d_sorted_xyz, const uint32_t 
 // merged-window kernel, so the default choice by density does not include it.
 static bool fused_wanted(uint64_t n, int x_lo, int x_hi)
 {
-    return g_variant_count == 7 && g_variant_bin == 1 && n != 0 && x_lo != x_hi;
+    return variant_count() == 7 && variant_bin() == 1 && n != 0 && x_lo != x_hi;
 }
 
 static const uint32_t *fused_gate_words(void *d_workspace, uint64_t n) { return carve_lds_ws(d_workspace, n).big_count + 2; }
@@ -890,6 +913,7 @@ struct pc_context {
     const float *export_points;
     int exported;
     uint32_t export_start[PC_L_BINS];
+    int variant_bin, variant_count;      // this context's own algorithm variants, or -1: the process-wide ones
 };
 
 extern "C" int pc_create(pc_context **out, int device, uint64_t expected_points)
@@ -908,6 +932,7 @@ extern "C" int pc_create(pc_context **out, int device, uint64_t expected_points)
     c->x_lo = 0;
     c->x_hi = PC_NLAYERS;
     c->geo = geom_default();
+    c->variant_bin = c->variant_count = -1;
     c->cap = expected_points ? expected_points : (1u << 20);
     pthread_rwlock_init(&c->lock, NULL);
     pthread_mutex_init(&c->reserve, NULL);
@@ -937,6 +962,21 @@ extern "C" int pc_set_slab(pc_context *c, int x_lo, int x_hi)
     c->x_lo = x_lo;
     c->x_hi = x_hi;
     return PC_OK;
+}
+
+extern "C" int pc_context_set_variant(pc_context *c, const char *name, int value)
+{
+    if (!c) return pc_fail(PC_ERR_ARG, "pc_context_set_variant: null context");
+    int which = -1;
+    int rc = check_variant("pc_context_set_variant", name, value, &which);
+    if (rc) return rc;
+    if (which < 0) return pc_fail(PC_ERR_ARG, "pc_context_set_variant: '%s' is not a per-context choice (\"bin\" and \"count\" are)", name);
+    pthread_rwlock_wrlock(&c->lock);
+    if (c->finished) rc = pc_fail(PC_ERR_STATE, "pc_context_set_variant after pc_finish");
+    else if (which == 0) c->variant_bin = value;
+    else c->variant_count = value;
+    pthread_rwlock_unlock(&c->lock);
+    return rc;
 }
 
 extern "C" int pc_set_geometry(pc_context *c, const pc_geometry *g)
@@ -1329,6 +1369,11 @@ static int finish_work(pc_context *c)
     if (c->append_rc) return pc_fail(c->append_rc, "an earlier append failed (%s): the context holds no usable point set", c->append_msg);
     PC_HIP(hipSetDevice(c->device));
     geo_scope scope(c->geo);
+    struct variant_scope {
+        int bin, count;
+        variant_scope(int b, int k) : bin(t_variant_bin), count(t_variant_count) { t_variant_bin = b; t_variant_count = k; }
+        ~variant_scope() { t_variant_bin = bin; t_variant_count = count; }
+    } variants(c->variant_bin, c->variant_count);
     const uint64_t n = c->size;
     finish_bufs b;
     const size_t wsb = pc_workspace_bytes(n);
@@ -1352,7 +1397,7 @@ static int finish_work(pc_context *c)
     } drain{s};
     // the histogram kernels of the appends ran on the null stream or on streams their callers have synchronised
     // (pc_append_device waits for its copy AND the kernel queued behind it): this stream is ordered behind them
-    const bool counted = c->layers_counted && g_variant_bin == 1;
+    const bool counted = c->layers_counted && variant_bin() == 1;
     PC_HIP(hipMemsetAsync(b.res, 0, 16, s));
     if (!counted) PC_HIP(hipMemsetAsync(c->d_status, 0, 4, s));      // (the counts taken under another geometry may have flagged points)
     PC_HIP(hipEventRecord(b.ev[0], s));

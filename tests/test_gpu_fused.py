@@ -75,3 +75,27 @@ def test_fused_streaming_interface(psa, oracle):
         with pytest.raises(psa.PairCountError) as e:
             pc.finish()
         assert e.value.code == -3
+
+
+def test_two_contexts_hold_different_variants(psa, oracle):
+    """pc_context_set_variant: a context keeps its own choice whatever the process-wide knobs say when it is
+    finished -- here the fused pair test in one context (its test count comes from the kernel) and the atomic
+    scatter + thread-per-particle kernels in the other."""
+    rng = np.random.default_rng(13)
+    pts = _slab(rng, 500_000, 10, 12)
+    want, want_tests = oracle.count_pairs(pts)[:2]
+    a, b = psa.PairCounter(0, len(pts)), psa.PairCounter(0, len(pts))
+    a.set_variant("count", 7)
+    b.set_variant("bin", 0)
+    b.set_variant("count", 0)
+    with pytest.raises(psa.PairCountError):
+        a.set_variant("segments", 5)            # a process-wide size, not a per-context choice
+    a.append(pts)
+    b.append(pts)
+    psa.set_variant("count", 3)                 # the process-wide choice differs from both
+    assert b.finish() == want and a.finish() == want
+    assert a.tests() == b.tests() == want_tests
+    with pytest.raises(psa.PairCountError):
+        a.set_variant("count", 5)               # after pc_finish
+    a.close()
+    b.close()
