@@ -365,9 +365,17 @@ static pc_lds_ws carve_lds_ws(void *ws, uint64_t n)
 // (layer_counts: the [NREP][404] counts of L1 if they were taken while the points arrived, else null)
 // home layers [home_lo, home_hi) and `fused`: the call may be served by the fused pair test (level Z then runs
 // only if a pencil neighbourhood of the home layers exceeds that kernel's capacity: decided on the device)
+// What a whole-path call wants cleared before its pair test: the work counters of the pair test and the result.
+// Level X's scan kernel does it on the way (no fill launches of their own).
+struct zero_request {
+    unsigned int *words = nullptr;
+    uint32_t n = 0;
+    unsigned long long *out = nullptr;
+};
+
 static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *table, void *ws,
                    int32_t *d_status, hipStream_t s, int layer_lo, int layer_hi, const uint32_t *layer_counts,
-                   int home_lo, int home_hi, bool fused)
+                   int home_lo, int home_hi, bool fused, const zero_request &zero)
 {
     pc_lds_ws w = carve_lds_ws(ws, n);
     uint32_t *const gate_words = w.big_count + 2;                       // pc_fused_serves: [0] largest neighbourhood, [1] capacity
@@ -379,7 +387,7 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
     else if (n) PC_LAUNCH("pc_l1_hist_x", pc_l1_hist_x, dim3(grid_for(n, PC_L_TILE, 2048)), dim3(PC_L_TPB), s,
                           d_xyz, n, w.layer_count, d_status, t_geo);
     PC_LAUNCH("pc_l2_scan_x", pc_l2_scan_x, dim3(1), dim3(512), s, w.layer_count, w.layer_start, w.layer_cursor,
-              w.layer_tile, w.tile_layer, gate_words + 1, (uint32_t)PC_F_CAP);
+              w.layer_tile, w.tile_layer, gate_words + 1, (uint32_t)PC_F_CAP, zero.words, zero.n, zero.out);
     if (n) {
         PC_LAUNCH("pc_l3_partition_x", pc_l36_partition<0>, dim3(tiles), dim3(PC_L_XTPB), s, d_xyz, n, d_sorted,
                   w.layer_start, w.layer_tile, w.tile_layer, w.layer_cursor, w.ycell, t_geo);
@@ -391,37 +399,36 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
     const bool sparse = n * 2 <= occupied_pencils * PC_L7_CAP_SPARSE;
     PC_LAUNCH("pc_l5_scan_y", pc_l5_scan_y, dim3(PC_NBB), dim3(512), s, w.pencil_count, w.layer_start,
               w.pencil_start, w.pencil_cursor, (uint32_t)(sparse ? PC_L7_CAP_SPARSE : PC_L7_CAP), w.big_count, w.big_list,
-              home_lo, home_hi, gate_words);
+              home_lo, home_hi, gate_words, layer_lo, layer_hi, (uint32_t)PC_L7B_CAP_LARGE, w.huge_list, w.huge_count);
     if (n)
         PC_LAUNCH("pc_l6_partition_y", pc_l36_partition<1>, dim3(tiles + PC_NBB), dim3(PC_L_PTPB), s, d_sorted, n,
                   w.tmp, w.layer_start, w.layer_tile, w.tile_layer, w.pencil_cursor, w.ycell, t_geo);
+    // Level Z in three launches.  Pencils too big for a wave are listed by L5 (one workgroup each: two size classes,
+    // fixed grids walk the list), those too big for a workgroup on a second list (tile-parallel histogram, scan,
+    // partition).  The three steps of the latter ride at the end of the three grids: see L7H in pc_bin_lds.h.
     const uint32_t first_pencil = (uint32_t)layer_lo * PC_NBB, end_pencil = (uint32_t)(layer_hi + 1) * PC_NBB;
-    const dim3 l7_grid((end_pencil - first_pencil + PC_L7_WAVES - 1) / PC_L7_WAVES);
+    const uint32_t l7_blocks = (end_pencil - first_pencil + PC_L7_WAVES - 1) / PC_L7_WAVES;
+    const dim3 l7_grid(l7_blocks + PC_L7H_GRID);
     if (sparse)
         PC_LAUNCH("pc_l7_sort_pencils", pc_l7_sort_pencils<PC_L7_CAP_SPARSE>, l7_grid, dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted,
-                  w.pencil_start, table, first_pencil, end_pencil, d_status, t_geo, fgate);
+                  w.pencil_start, table, first_pencil, end_pencil, d_status, t_geo, fgate, l7_blocks, w.big_count + 1, w.huge_list,
+                  w.huge_count);
     else
         PC_LAUNCH("pc_l7_sort_pencils", pc_l7_sort_pencils<PC_L7_CAP>, l7_grid, dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted,
-                  w.pencil_start, table, first_pencil, end_pencil, d_status, t_geo, fgate);
-    // pencils too big for a wave (listed by L5): one workgroup each, fixed grids walk the list, one per size class
+                  w.pencil_start, table, first_pencil, end_pencil, d_status, t_geo, fgate, l7_blocks, w.big_count + 1, w.huge_list,
+                  w.huge_count);
     auto small = pc_l7b_sort_big_pencils<PC_L7B_CAP_SMALL, PC_L7B_TPB_SMALL>;
     auto large = pc_l7b_sort_big_pencils<PC_L7B_CAP_LARGE, PC_L7B_TPB_LARGE>;
     const launch_sizes *sizes = nullptr;
     const int rc_sizes = launch_sizes_of_current_device(&sizes);
     if (rc_sizes) return rc_sizes;
-    PC_LAUNCH("pc_l7b_sort_big_pencils", small, dim3(sizes->l7b_small), dim3(PC_L7B_TPB_SMALL), s, w.tmp, d_sorted, w.pencil_start, table,
-              w.big_count, w.big_list, first_pencil, end_pencil, 0u, (uint32_t)PC_L7B_CAP_SMALL,
-              (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, d_status, t_geo, fgate);
-    PC_LAUNCH("pc_l7b_sort_bigger_pencils", large, dim3(sizes->l7b_large), dim3(PC_L7B_TPB_LARGE), s, w.tmp, d_sorted, w.pencil_start, table,
-              w.big_count, w.big_list, first_pencil, end_pencil, (uint32_t)PC_L7B_CAP_SMALL, (uint32_t)PC_L7B_CAP_LARGE,
-              w.big_count + 1, w.huge_list, w.huge_count, d_status, t_geo, fgate);
-    // pencils beyond a workgroup's capacity (listed just now): tile-parallel histogram, scan, partition
-    PC_LAUNCH("pc_l7h_hist", pc_l7h_hist, dim3(PC_L7H_GRID), dim3(PC_L_TPB), s, w.tmp, w.pencil_start, w.big_count + 1,
-              w.huge_list, w.huge_count, d_status, t_geo, fgate);
-    PC_LAUNCH("pc_l7h_scan", pc_l7h_scan, dim3(256), dim3(64), s, w.pencil_start, w.big_count + 1, w.huge_list,
-              w.huge_count, w.huge_cursor, table, fgate);
-    PC_LAUNCH("pc_l7h_partition", pc_l7h_partition, dim3(PC_L7H_GRID), dim3(PC_L_PTPB), s, w.tmp, d_sorted, w.pencil_start,
-              w.big_count + 1, w.huge_list, w.huge_cursor, t_geo, fgate);
+    PC_LAUNCH("pc_l7b_sort_big_pencils", small, dim3(sizes->l7b_small + PC_L7H_SCAN_GRID), dim3(PC_L7B_TPB_SMALL), s, w.tmp, d_sorted,
+              w.pencil_start, table, w.big_count, w.big_list, first_pencil, end_pencil, 0u, (uint32_t)PC_L7B_CAP_SMALL,
+              (uint32_t)sizes->l7b_small, w.big_count + 1, w.huge_list, w.huge_count, w.huge_cursor, d_status, t_geo, fgate);
+    PC_LAUNCH("pc_l7b_sort_bigger_pencils", large, dim3(sizes->l7b_large + PC_L7H_GRID), dim3(PC_L7B_TPB_LARGE), s, w.tmp, d_sorted,
+              w.pencil_start, table, w.big_count, w.big_list, first_pencil, end_pencil, (uint32_t)PC_L7B_CAP_SMALL,
+              (uint32_t)PC_L7B_CAP_LARGE, (uint32_t)sizes->l7b_large, w.big_count + 1, w.huge_list, w.huge_count, w.huge_cursor,
+              d_status, t_geo, fgate);
     PC_HIP(hipGetLastError());
     return PC_OK;
 }
@@ -502,7 +509,7 @@ extern "C" int pc_cell_keys_device(const float *d_xyz, uint64_t n, uint32_t *d_k
 static int bin_layers(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
                       uint32_t *d_cell_start, void *d_workspace, size_t workspace_bytes,
                       int32_t *d_status, void *stream, int layer_lo, int layer_hi, const uint32_t *layer_counts = nullptr,
-                      int home_lo = 0, int home_hi = 0, bool fused = false);
+                      int home_lo = 0, int home_hi = 0, bool fused = false, zero_request *zero = nullptr);
 extern "C" int pc_bin_device(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
                              uint32_t *d_cell_start, void *d_workspace, size_t workspace_bytes,
                              int32_t *d_status, void *stream);
@@ -520,7 +527,7 @@ extern "C" int pc_bin_device(const float *d_xyz, uint64_t n, float *d_sorted_xyz
 static int bin_layers(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
                       uint32_t *d_cell_start, void *d_workspace, size_t workspace_bytes,
                       int32_t *d_status, void *stream, int layer_lo, int layer_hi, const uint32_t *layer_counts,
-                      int home_lo, int home_hi, bool fused)
+                      int home_lo, int home_hi, bool fused, zero_request *zero)
 {
     if (!d_cell_start || !d_status || !d_workspace)
         return pc_fail(PC_ERR_ARG, "pc_bin_device: null pointer");
@@ -530,9 +537,12 @@ static int bin_layers(const float *d_xyz, uint64_t n, float *d_sorted_xyz,
         return pc_fail(PC_ERR_ARG, "pc_bin_device: workspace %zu < %zu bytes", workspace_bytes,
                        pc_workspace_bytes(n));
     hipStream_t s = (hipStream_t)stream;
-    if (variant_bin() == 1)
-        return bin_lds(d_xyz, n, d_sorted_xyz, d_cell_start, d_workspace, d_status, s, layer_lo, layer_hi, layer_counts, home_lo,
-                       home_hi, fused);
+    if (variant_bin() == 1) {
+        const int rc = bin_lds(d_xyz, n, d_sorted_xyz, d_cell_start, d_workspace, d_status, s, layer_lo, layer_hi, layer_counts, home_lo,
+                               home_hi, fused, zero ? *zero : zero_request());
+        if (rc == PC_OK && zero) *zero = zero_request();     // served
+        return rc;
+    }
     const uint64_t m = PC_NCELLS + 2;
     uint32_t *keys = (uint32_t *)d_workspace;
     uint32_t *sums = (uint32_t *)((char *)d_workspace + align_up((size_t)n * 4 + 4, 256));
@@ -617,9 +627,10 @@ static int check_slab(const char *who, int x_lo, int x_hi)
 }
 
 // fgate: the switch of a whole-path call that the fused pair test may serve (see pc_fused_serves), else null
+// queue_zeroed: the work counters were cleared on this stream already (a whole-path call has level X's scan do it)
 static int count_sorted(const float *d_sorted_xyz, const uint32_t *d_cell_start,
                         uint64_t n, int x_lo, int x_hi, uint64_t *d_npairs,
-                        void *stream, const uint32_t *fgate)
+                        void *stream, const uint32_t *fgate, bool queue_zeroed = false)
 {
     if (!d_cell_start || !d_npairs) return pc_fail(PC_ERR_ARG, "pc_count_sorted_device: null pointer");
     if (!d_sorted_xyz && n) return pc_fail(PC_ERR_ARG, "pc_count_sorted_device: null point array");
@@ -646,7 +657,7 @@ static int count_sorted(const float *d_sorted_xyz, const uint32_t *d_cell_start,
         int rc2 = count_queue(&queue);
         if (rc2) return rc2;
         const uint32_t seg_cap = (uint32_t)g_segments.load(), heavy_cap = (uint32_t)g_heavy.load();   // one read each per call
-        PC_HIP(hipMemsetAsync(queue, 0, PC_G_FLAGS * sizeof(unsigned int), (hipStream_t)stream));   // all counters
+        if (!queue_zeroed) PC_HIP(hipMemsetAsync(queue, 0, PC_G_FLAGS * sizeof(unsigned int), (hipStream_t)stream));   // all counters
         const dim3 plan_grid(((x_hi - x_lo) * PC_NLAYERS + PC_G_PLAN_PENCILS - 1) / PC_G_PLAN_PENCILS);
         // a pencil holding more than four average pencils (and at least 512 points) counts as dense; an input with
         // over a quarter of its points in such pencils is clustered: the merged-window kernel then leaves the
@@ -777,17 +788,24 @@ extern "C" int pc_count_pairs_device(const float *d_xyz, uint64_t n, int x_lo, i
     if (rc) return rc;
     // home layers [x_lo, x_hi) and the halo layer x_hi are all the pair test reads
     const bool fused = fused_wanted(n, x_lo, x_hi);
+    // the result and the pair test's work counters are cleared by a binning kernel on its way (LDS variant), else here
+    zero_request zero;
+    rc = count_queue(&zero.words);
+    if (rc) return rc;
+    zero.n = PC_G_FLAGS;
+    zero.out = (unsigned long long *)d_npairs;
     rc = bin_layers(d_xyz, n, d_sorted_xyz, d_cell_start, d_workspace, workspace_bytes, d_status, stream, x_lo,
                     x_hi < PC_NLAYERS ? x_hi : PC_NBB - 1,         // the last slab also gets the empty padding layers
-                    nullptr, x_lo, x_hi, fused);
+                    nullptr, x_lo, x_hi, fused, &zero);
     if (rc) return rc;
-    PC_HIP(hipMemsetAsync(d_npairs, 0, sizeof(uint64_t), (hipStream_t)stream));
+    const bool zeroed = zero.out == nullptr;
+    if (!zeroed) PC_HIP(hipMemsetAsync(d_npairs, 0, sizeof(uint64_t), (hipStream_t)stream));
     if (fused) {
         rc = count_fused(d_workspace, n, x_lo, x_hi, d_npairs, nullptr, d_status, (hipStream_t)stream);
         if (rc) return rc;
     }
     return count_sorted(d_sorted_xyz, d_cell_start, n, x_lo, x_hi, d_npairs, stream,
-                        fused ? fused_gate_words(d_workspace, n) : nullptr);
+                        fused ? fused_gate_words(d_workspace, n) : nullptr, zeroed);
 }
 
 extern "C" int pc_count_pairs_geometry_device(const pc_geometry *g, const float *d_xyz, uint64_t n, int x_lo, int x_hi,
@@ -1291,7 +1309,7 @@ extern "C" int pc_export_layers(pc_context *c, const float **d_points, uint32_t 
                              w.layer_count, c->d_status, t_geo);
         }
         PC_LAUNCH("pc_l2_scan_x", pc_l2_scan_x, dim3(1), dim3(512), s, w.layer_count, w.layer_start, w.layer_cursor,
-                  w.layer_tile, w.tile_layer, w.big_count + 3, 0u);
+                  w.layer_tile, w.tile_layer, w.big_count + 3, 0u, (unsigned int *)nullptr, 0u, (unsigned long long *)nullptr);
         if (n) PC_LAUNCH("pc_l3_partition_x", pc_l36_partition<0>, dim3((unsigned)((n + PC_L_TILE - 1) / PC_L_TILE)), dim3(PC_L_XTPB), s,
                          c->d_xyz, n, w.tmp, w.layer_start, w.layer_tile, w.tile_layer, w.layer_cursor, w.ycell, t_geo);
         PC_HIP(hipGetLastError());

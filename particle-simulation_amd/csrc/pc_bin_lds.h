@@ -134,9 +134,14 @@ pc_l1_hist_x_range(const float *__restrict__ xyz, uint64_t first, uint64_t end, 
 __global__ void __launch_bounds__(512)
 pc_l2_scan_x(const uint32_t *__restrict__ layer_count, uint32_t *__restrict__ layer_start,
              uint32_t *__restrict__ layer_cursor, uint32_t *__restrict__ layer_tile,
-             uint32_t *__restrict__ tile_layer, uint32_t *__restrict__ fused_cap_word, uint32_t fused_cap)
+             uint32_t *__restrict__ tile_layer, uint32_t *__restrict__ fused_cap_word, uint32_t fused_cap,
+             unsigned int *__restrict__ zero_words, uint32_t zero_n, unsigned long long *__restrict__ zero_out)
 {
     if (threadIdx.x == 0) *fused_cap_word = fused_cap;   // second word of the switch that pc_fused_serves reads
+    // A whole-path call clears the pair test's work counters and its result here instead of with two fill
+    // launches of their own (every launch costs about 6 us, a tenth of a small slab's step).
+    for (uint32_t k = threadIdx.x; k < zero_n; k += 512) zero_words[k] = 0u;
+    if (zero_out != nullptr && threadIdx.x == 0) *zero_out = 0ull;
     __shared__ uint32_t a[512], t[512];
     const int i = threadIdx.x;
     uint32_t rep[PC_L_NREP], c = 0;
@@ -210,11 +215,13 @@ pc_l4_hist_y(const uint16_t *__restrict__ ycell, const uint32_t *__restrict__ la
 // record (atomic maximum into *max5) the largest number of points any home pencil
 // (i,j) of theirs has in its neighbourhood (i,j) (i,j+1) (i+1,j-1..j+1): what the
 // fused pair test must hold in LDS at once, and the switch between it and the classic kernels.
+// Pencils too big for a wave of L7 go on big_list, those too big for a workgroup of L7B also on huge_list.
 __global__ void __launch_bounds__(512)
 pc_l5_scan_y(const uint32_t *__restrict__ pencil_count, const uint32_t *__restrict__ layer_start,
              uint32_t *__restrict__ pencil_start, uint32_t *__restrict__ pencil_cursor,
              uint32_t wave_cap, uint32_t *__restrict__ big_count, uint32_t *__restrict__ big_list,
-             int x_lo, int x_hi, uint32_t *__restrict__ max5)
+             int x_lo, int x_hi, uint32_t *__restrict__ max5,
+             int sort_lo, int sort_hi, uint32_t huge_above, uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count)
 {
     __shared__ uint32_t a[512], own[512], above[512], most;
     const int j = threadIdx.x, layer = blockIdx.x;
@@ -247,6 +254,13 @@ pc_l5_scan_y(const uint32_t *__restrict__ pencil_count, const uint32_t *__restri
     if (j < PC_NBB) {
         pencil_start[layer * PC_NBB + j] = ex;
         if (c > wave_cap) big_list[atomicAdd(big_count, 1u)] = (uint32_t)(layer * PC_NBB + j);   // sorted by L7B
+        // more points than a workgroup of L7B sorts, in a layer [sort_lo, sort_hi] whose pencils are wanted sorted:
+        // on the list of the tile-parallel sort (L7H), with its row of cell counts cleared (many points in one place: rare)
+        if (c > huge_above && layer >= sort_lo && layer <= sort_hi) {
+            const uint32_t slot = atomicAdd(big_count + 1, 1u);
+            huge_list[slot] = (uint32_t)(layer * PC_NBB + j);
+            for (int k = 0; k < PC_L_BINS; k++) huge_count[(uint64_t)slot * PC_L_BINS + k] = 0u;
+        }
         uint32_t run = ex;
 #pragma unroll
         for (int g = 0; g < PC_L_NREP; g++) {          // replica sub-regions of the pencil, as in level X
@@ -446,15 +460,185 @@ __device__ __forceinline__ void pc_l7_scan_bins(uint32_t *hist, int lane)
     }
 }
 
+// ---- L7H: pencils too big for one workgroup, sorted by all of them -------------
+// A pencil with more than PC_L7B_CAP_LARGE points (many points in one place) is one more
+// level of the same bucket sort: tiles of 4096 points, histogram of z cells (LDS, then
+// one global atomic per tile and cell), scan, and a partition pass that sorts each tile
+// by cell in LDS and writes every cell's run with coalesced stores.  The pencils are
+// listed by L5; tile c of list entry h is taken by workgroup (c + 7 h) mod (workgroups of
+// the role), so that many entries with few tiles each spread out as well as one entry with
+// thousands.
+// The three steps are not launches of their own: an input without such pencils (nearly
+// every input) would pay three launches that find nothing to do, about 6 us each.  They
+// ride as extra workgroups ("roles") at the end of the grids of kernels that run anyway
+// and in the order the steps need: the histogram with L7, the scan with the small L7B
+// instantiation, the partition with the large one.  A role's workgroups are numbered
+// blk = 0 .. nblk-1.
+#define PC_L7H_GRID 1024                               // workgroups of the histogram and of the partition role
+#define PC_L7H_SCAN_GRID 64                            // and of the scan role (one wave of each works)
+__device__ __forceinline__ uint32_t pc_l7h_first_tile(uint32_t h, uint32_t blk, uint32_t nblk)
+{
+    return (blk + nblk - (7u * h) % nblk) % nblk;
+}
+
+// histogram role: TPB threads, h_lds = PC_L_BINS words of LDS
+template <int TPB>
+__device__ __forceinline__ void pc_l7h_hist_role(uint32_t blk, uint32_t nblk, uint32_t *h_lds, const float *__restrict__ src,
+                                                 const uint32_t *__restrict__ pencil_start, const uint32_t *__restrict__ huge_n,
+                                                 const uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count,
+                                                 int32_t *__restrict__ status, const pc_geom &geo)
+{
+    const uint32_t entries = *huge_n;
+    if (entries == 0) return;
+    constexpr int BATCH = 8, PPT = PC_L_TILE / TPB;
+    static_assert(PPT % BATCH == 0, "tile / threads must be a multiple of the load batch");
+    const int tid = threadIdx.x;
+    bool bad = false;
+    for (uint32_t h = 0; h < entries; h++) {
+        const uint32_t pencil = huge_list[h];
+        const uint32_t base = pencil_start[pencil], n = pencil_start[pencil + 1] - base;
+        const uint32_t ntiles = (n + PC_L_TILE - 1) / PC_L_TILE;
+        const pc_pt3 *g = reinterpret_cast<const pc_pt3 *>(src) + base;
+        for (uint32_t t = pc_l7h_first_tile(h, blk, nblk); t < ntiles; t += nblk) {
+            const uint32_t first = t * PC_L_TILE, cnt = min((uint32_t)PC_L_TILE, n - first);
+            __syncthreads();
+            for (int b = tid; b < PC_L_BINS; b += TPB) h_lds[b] = 0;
+            __syncthreads();
+            for (int j0 = 0; j0 < PPT; j0 += BATCH) {
+                float zs[BATCH];
+#pragma unroll
+                for (int j = 0; j < BATCH; j++) zs[j] = g[first + min((uint32_t)(tid + (j0 + j) * TPB), cnt - 1)].z;
+#pragma unroll
+                for (int j = 0; j < BATCH; j++) {
+                    if ((uint32_t)(tid + (j0 + j) * TPB) < cnt) {
+                        const int k = pc_cell_index(zs[j], geo);
+                        if ((unsigned)k < (unsigned)geo.ncell) atomicAdd(&h_lds[k], 1u);
+                        else bad = true;
+                    }
+                }
+            }
+            __syncthreads();
+            for (int b = tid; b < 400; b += TPB)
+                if (h_lds[b]) atomicAdd(&huge_count[(uint64_t)h * PC_L_BINS + b], h_lds[b]);
+        }
+    }
+    if (bad) atomicOr(status, 1);
+}
+
+// scan role: wave 0 of each workgroup (hist = PC_L_BINS words of LDS); also writes the pencils' table slices
+__device__ __forceinline__ void pc_l7h_scan_role(uint32_t blk, uint32_t nblk, uint32_t *hist, const uint32_t *__restrict__ pencil_start,
+                                                 const uint32_t *__restrict__ huge_n, const uint32_t *__restrict__ huge_list,
+                                                 const uint32_t *__restrict__ huge_count, uint32_t *__restrict__ huge_cursor,
+                                                 uint32_t *__restrict__ table)
+{
+    const uint32_t entries = *huge_n;
+    if (threadIdx.x >= 64) return;
+    for (uint32_t h = blk; h < entries; h += nblk) {
+        const uint32_t pencil = huge_list[h], base = pencil_start[pencil];
+        for (int k = threadIdx.x; k < PC_L_BINS; k += 64) hist[k] = huge_count[(uint64_t)h * PC_L_BINS + k];
+        pc_wave_lds_sync();
+        pc_l7_scan_bins(hist, threadIdx.x);                // exclusive starts, in place
+        pc_wave_lds_sync();
+        uint32_t *slice = table + (uint64_t)pencil * PC_NBB;
+        for (int k = threadIdx.x; k < PC_L_BINS; k += 64) {
+            huge_cursor[(uint64_t)h * PC_L_BINS + k] = base + hist[k];
+            if (k < PC_NBB) slice[k] = base + hist[k];
+        }
+        pc_wave_lds_sync();
+    }
+}
+
+// partition role: PC_L_PTPB threads; LDS: buf = a tile of points (PC_L_TILE * 3 floats), bin_of (PC_L_TILE), three
+// arrays of PC_L_BINS words
+__device__ __forceinline__ void pc_l7h_partition_role(uint32_t blk, uint32_t nblk, float *buf, uint16_t *bin_of, uint32_t *hist,
+                                                      uint32_t *lstart, uint32_t *delta, const float *__restrict__ src,
+                                                      float *__restrict__ dst, const uint32_t *__restrict__ pencil_start,
+                                                      const uint32_t *__restrict__ huge_n, const uint32_t *__restrict__ huge_list,
+                                                      uint32_t *__restrict__ huge_cursor, const pc_geom &geo)
+{
+    const int tid = threadIdx.x;
+    const uint32_t entries = *huge_n;
+    for (uint32_t h = 0; h < entries; h++) {
+        const uint32_t pencil = huge_list[h];
+        const uint32_t base = pencil_start[pencil], n = pencil_start[pencil + 1] - base;
+        const uint32_t ntiles = (n + PC_L_TILE - 1) / PC_L_TILE;
+        uint32_t *cursor = huge_cursor + (uint64_t)h * PC_L_BINS;
+        for (uint32_t t = pc_l7h_first_tile(h, blk, nblk); t < ntiles; t += nblk) {
+            const uint32_t first = t * PC_L_TILE, cnt = min((uint32_t)PC_L_TILE, n - first);
+            const pc_pt3 *g = reinterpret_cast<const pc_pt3 *>(src) + base + first;
+            __syncthreads();                           // the previous tile's LDS reads are done
+            for (int b = tid; b < PC_L_BINS; b += PC_L_PTPB) hist[b] = 0;
+            pc_pt3 pt[PC_L_PPPT];
+#pragma unroll
+            for (int j = 0; j < PC_L_PPPT; j++) pt[j] = g[min((uint32_t)(tid + j * PC_L_PTPB), cnt - 1)];
+            __syncthreads();
+            uint32_t tag[PC_L_PPPT];                   // cell | rank << 10, or ~0 for "skip"
+#pragma unroll
+            for (int j = 0; j < PC_L_PPPT; j++) {
+                tag[j] = 0xFFFFFFFFu;
+                if ((uint32_t)(tid + j * PC_L_PTPB) < cnt) {
+                    const uint32_t b = (uint32_t)pc_cell_index(pt[j].z, geo);
+                    if (b < (unsigned)geo.ncell) tag[j] = b | (atomicAdd(&hist[b], 1u) << 10);
+                }
+            }
+            __syncthreads();
+            if (tid < 64) {                            // exclusive scan of the tile's cell counts
+                uint32_t c[7], sum = 0;
+#pragma unroll
+                for (int q = 0; q < 7; q++) {
+                    const int b = tid * 7 + q;
+                    c[q] = b < PC_L_BINS ? hist[b] : 0u;
+                    sum += c[q];
+                }
+                uint32_t run = pc_wave_incl_scan(sum) - sum;
+#pragma unroll
+                for (int q = 0; q < 7; q++) {
+                    const int b = tid * 7 + q;
+                    if (b < PC_L_BINS) lstart[b] = run;
+                    run += c[q];
+                }
+            }
+            __syncthreads();
+            for (int b = tid; b < PC_L_BINS; b += PC_L_PTPB) {      // claim global space: one atomic per non-empty cell
+                const uint32_t c = hist[b];
+                if (c) delta[b] = atomicAdd(&cursor[b], c) - lstart[b];
+            }
+#pragma unroll
+            for (int j = 0; j < PC_L_PPPT; j++) {
+                if (tag[j] != 0xFFFFFFFFu) {
+                    const uint32_t b = tag[j] & 1023u, pos = lstart[b] + (tag[j] >> 10);
+                    buf[3 * pos] = pt[j].x;
+                    buf[3 * pos + 1] = pt[j].y;
+                    buf[3 * pos + 2] = pt[j].z;
+                    bin_of[pos] = (uint16_t)b;
+                }
+            }
+            __syncthreads();
+            const uint32_t kept = lstart[PC_L_BINS - 1] + hist[PC_L_BINS - 1];
+            for (uint32_t d = tid; d < 3 * kept; d += PC_L_PTPB) {   // runs -> global, coalesced dwords
+                const uint32_t e = d / 3u;
+                const uint32_t slot = delta[bin_of[e]] + e;
+                dst[3 * (uint64_t)slot + (d - 3u * e)] = buf[d];
+            }
+        }
+    }
+}
+
 template <int CAP>
 __global__ void __launch_bounds__(PC_L7_WAVES * 64)
 pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
                    const uint32_t *__restrict__ pencil_start, uint32_t *__restrict__ table,
                    uint32_t first_pencil, uint32_t end_pencil, int32_t *__restrict__ status, const pc_geom geo,
-                   const uint32_t *__restrict__ fgate)
+                   const uint32_t *__restrict__ fgate, uint32_t sort_blocks, const uint32_t *__restrict__ huge_n,
+                   const uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count)
 {
     if (pc_fused_serves(fgate)) return;
     __shared__ uint32_t hist_all[PC_L7_WAVES][PC_L_BINS];
+    if (blockIdx.x >= sort_blocks) {                   // the workgroups behind the pencils': L7H's histogram (normally nothing to do)
+        pc_l7h_hist_role<PC_L7_WAVES * 64>(blockIdx.x - sort_blocks, gridDim.x - sort_blocks, hist_all[0], src, pencil_start, huge_n,
+                                           huge_list, huge_count, status, geo);
+        return;
+    }
     constexpr int PPL = CAP / 64;                      // points per lane
     __shared__ __attribute__((aligned(16))) float stage_all[PC_L7_WAVES][CAP * 3 + 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -531,7 +715,8 @@ pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
 // registers and an LDS copy in cell order like L7's.  Two instantiations share the
 // list: a small one (several workgroups per CU) takes the pencils of at most
 // PC_L7B_CAP_SMALL points, a large one those of up to PC_L7B_CAP_LARGE; what is
-// larger still, the large one lists for the tile-parallel kernels (L7H below).
+// larger still is on L5's second list and sorted tile by tile (L7H above).  The
+// first sort_blocks workgroups of the grid sort; the rest take a step of L7H.
 #define PC_L7B_CAP_SMALL 2048
 #define PC_L7B_TPB_SMALL 256
 #define PC_L7B_CAP_LARGE 8192
@@ -543,33 +728,37 @@ pc_l7b_sort_big_pencils(const float *__restrict__ src, float *__restrict__ dst,
                         const uint32_t *__restrict__ pencil_start, uint32_t *__restrict__ table,
                         const uint32_t *__restrict__ big_count, const uint32_t *__restrict__ big_list,
                         uint32_t first_pencil, uint32_t end_pencil, uint32_t n_above, uint32_t n_upto,
-                        uint32_t *__restrict__ huge_n, uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count,
+                        uint32_t sort_blocks, const uint32_t *__restrict__ huge_n, const uint32_t *__restrict__ huge_list,
+                        const uint32_t *__restrict__ huge_count, uint32_t *__restrict__ huge_cursor,
                         int32_t *__restrict__ status, const pc_geom geo, const uint32_t *__restrict__ fgate)
 {
     if (pc_fused_serves(fgate)) return;
     constexpr int PC_L7B_PPT = PC_L7B_CAP / PC_L7B_TPB;
     __shared__ uint32_t hist[PC_L_BINS];
     __shared__ float stage[PC_L7B_CAP * 3];
+    if (blockIdx.x >= sort_blocks) {                   // the workgroups behind the sorting ones: a step of L7H (normally nothing to do)
+        const uint32_t blk = blockIdx.x - sort_blocks, nblk = gridDim.x - sort_blocks;
+        if constexpr (PC_L7B_CAP == PC_L7B_CAP_SMALL)
+            pc_l7h_scan_role(blk, nblk, hist, pencil_start, huge_n, huge_list, huge_count, huge_cursor, table);
+        else {
+            static_assert(PC_L7B_CAP == PC_L7B_CAP_SMALL || PC_L7B_TPB == PC_L_PTPB, "the partition role runs with PC_L_PTPB threads");
+            static_assert(PC_L7B_CAP == PC_L7B_CAP_SMALL ||
+                          PC_L7B_CAP * 3 >= PC_L_TILE * 3 + PC_L_TILE / 2 + 2 * PC_L_BINS, "the partition role's arrays lie inside `stage`");
+            uint32_t *words = reinterpret_cast<uint32_t *>(stage + PC_L_TILE * 3 + PC_L_TILE / 2);
+            pc_l7h_partition_role(blk, nblk, stage, reinterpret_cast<uint16_t *>(stage + PC_L_TILE * 3), hist, words, words + PC_L_BINS,
+                                  src, dst, pencil_start, huge_n, huge_list, huge_cursor, geo);
+        }
+        return;
+    }
     const int tid = threadIdx.x;
     const uint32_t nbig = *big_count;
     bool bad = false;
-    for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
+    for (uint32_t b = blockIdx.x; b < nbig; b += sort_blocks) {
         const uint32_t pencil = big_list[b];
         if (pencil < first_pencil || pencil >= end_pencil) continue;          // workgroup-uniform
         const uint32_t base = pencil_start[pencil], n = pencil_start[pencil + 1] - base;
         if (n <= n_above) continue;                                           // the other instantiation's
-        if (n > n_upto) {
-            // more than a workgroup sorts: the large instantiation lists the pencil for the tile-parallel kernels
-            // (pc_l7h_*) and clears its row of cell counts; the small one leaves it alone
-            if (huge_n != nullptr) {
-                __shared__ uint32_t slot;
-                __syncthreads();
-                if (tid == 0) { slot = atomicAdd(huge_n, 1u); huge_list[slot] = pencil; }
-                __syncthreads();
-                for (int k = tid; k < PC_L_BINS; k += PC_L7B_TPB) huge_count[(uint64_t)slot * PC_L_BINS + k] = 0;
-            }
-            continue;
-        }
+        if (n > n_upto) continue;                                             // the other instantiation's, or L7H's (listed by L5)
         uint32_t *slice = table + (uint64_t)pencil * PC_NBB;
         const pc_pt3 *g = reinterpret_cast<const pc_pt3 *>(src) + base;
         __syncthreads();                                                     // previous pencil's LDS reads are done
@@ -607,157 +796,4 @@ pc_l7b_sort_big_pencils(const float *__restrict__ src, float *__restrict__ dst,
         }
     }
     if (bad) atomicOr(status, 1);
-}
-
-// ---- L7H: pencils too big for one workgroup, sorted by all of them -------------
-// A pencil with more than PC_L7B_CAP_LARGE points (many points in one place) is one more
-// level of the same bucket sort: tiles of 4096 points, histogram of z cells (LDS, then
-// one global atomic per tile and cell), scan, and a partition pass that sorts each tile
-// by cell in LDS and writes every cell's run with coalesced stores.  The pencils come
-// from the list the large L7B instantiation made; tile c of list entry h is taken by
-// workgroup (c + 7 h) mod gridDim, so that many entries with few tiles each spread out
-// over the grid as well as one entry with thousands.  Without such pencils the three
-// launches return at once.
-#define PC_L7H_GRID 1024
-__device__ __forceinline__ uint32_t pc_l7h_first_tile(uint32_t h)
-{
-    return (blockIdx.x + gridDim.x - (7u * h) % gridDim.x) % gridDim.x;
-}
-
-__global__ void __launch_bounds__(PC_L_TPB)
-pc_l7h_hist(const float *__restrict__ src, const uint32_t *__restrict__ pencil_start, const uint32_t *__restrict__ huge_n,
-            const uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count, int32_t *__restrict__ status, const pc_geom geo,
-            const uint32_t *__restrict__ fgate)
-{
-    if (pc_fused_serves(fgate)) return;
-    __shared__ uint32_t h_lds[PC_L_BINS];
-    const uint32_t entries = *huge_n;
-    bool bad = false;
-    for (uint32_t h = 0; h < entries; h++) {
-        const uint32_t pencil = huge_list[h];
-        const uint32_t base = pencil_start[pencil], n = pencil_start[pencil + 1] - base;
-        const uint32_t ntiles = (n + PC_L_TILE - 1) / PC_L_TILE;
-        const pc_pt3 *g = reinterpret_cast<const pc_pt3 *>(src) + base;
-        for (uint32_t t = pc_l7h_first_tile(h); t < ntiles; t += gridDim.x) {
-            const uint32_t first = t * PC_L_TILE, cnt = min((uint32_t)PC_L_TILE, n - first);
-            __syncthreads();
-            for (int b = threadIdx.x; b < PC_L_BINS; b += PC_L_TPB) h_lds[b] = 0;
-            __syncthreads();
-            float zs[PC_L_PPT];
-#pragma unroll
-            for (int j = 0; j < PC_L_PPT; j++) zs[j] = g[first + min((uint32_t)(threadIdx.x + j * PC_L_TPB), cnt - 1)].z;
-#pragma unroll
-            for (int j = 0; j < PC_L_PPT; j++) {
-                if ((uint32_t)(threadIdx.x + j * PC_L_TPB) < cnt) {
-                    const int k = pc_cell_index(zs[j], geo);
-                    if ((unsigned)k < (unsigned)geo.ncell) atomicAdd(&h_lds[k], 1u);
-                    else bad = true;
-                }
-            }
-            __syncthreads();
-            for (int b = threadIdx.x; b < 400; b += PC_L_TPB)
-                if (h_lds[b]) atomicAdd(&huge_count[(uint64_t)h * PC_L_BINS + b], h_lds[b]);
-        }
-    }
-    if (bad) atomicOr(status, 1);
-}
-
-__global__ void __launch_bounds__(64)
-pc_l7h_scan(const uint32_t *__restrict__ pencil_start, const uint32_t *__restrict__ huge_n, const uint32_t *__restrict__ huge_list,
-            const uint32_t *__restrict__ huge_count, uint32_t *__restrict__ huge_cursor, uint32_t *__restrict__ table,
-            const uint32_t *__restrict__ fgate)
-{
-    if (pc_fused_serves(fgate)) return;
-    __shared__ uint32_t hist[PC_L_BINS];
-    const uint32_t entries = *huge_n;
-    for (uint32_t h = blockIdx.x; h < entries; h += gridDim.x) {
-        const uint32_t pencil = huge_list[h], base = pencil_start[pencil];
-        for (int k = threadIdx.x; k < PC_L_BINS; k += 64) hist[k] = huge_count[(uint64_t)h * PC_L_BINS + k];
-        pc_wave_lds_sync();
-        pc_l7_scan_bins(hist, threadIdx.x);                // exclusive starts, in place
-        pc_wave_lds_sync();
-        uint32_t *slice = table + (uint64_t)pencil * PC_NBB;
-        for (int k = threadIdx.x; k < PC_L_BINS; k += 64) {
-            huge_cursor[(uint64_t)h * PC_L_BINS + k] = base + hist[k];
-            if (k < PC_NBB) slice[k] = base + hist[k];
-        }
-        pc_wave_lds_sync();
-    }
-}
-
-__global__ void __launch_bounds__(PC_L_PTPB)
-pc_l7h_partition(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ pencil_start,
-                 const uint32_t *__restrict__ huge_n, const uint32_t *__restrict__ huge_list,
-                 uint32_t *__restrict__ huge_cursor, const pc_geom geo, const uint32_t *__restrict__ fgate)
-{
-    if (pc_fused_serves(fgate)) return;
-    __shared__ float buf[PC_L_TILE * 3];              // the tile sorted by cell
-    __shared__ uint16_t bin_of[PC_L_TILE];
-    __shared__ uint32_t hist[PC_L_BINS], lstart[PC_L_BINS], delta[PC_L_BINS];
-    const int tid = threadIdx.x;
-    const uint32_t entries = *huge_n;
-    for (uint32_t h = 0; h < entries; h++) {
-        const uint32_t pencil = huge_list[h];
-        const uint32_t base = pencil_start[pencil], n = pencil_start[pencil + 1] - base;
-        const uint32_t ntiles = (n + PC_L_TILE - 1) / PC_L_TILE;
-        uint32_t *cursor = huge_cursor + (uint64_t)h * PC_L_BINS;
-        for (uint32_t t = pc_l7h_first_tile(h); t < ntiles; t += gridDim.x) {
-            const uint32_t first = t * PC_L_TILE, cnt = min((uint32_t)PC_L_TILE, n - first);
-            const pc_pt3 *g = reinterpret_cast<const pc_pt3 *>(src) + base + first;
-            __syncthreads();                           // the previous tile's LDS reads are done
-            for (int b = tid; b < PC_L_BINS; b += PC_L_PTPB) hist[b] = 0;
-            pc_pt3 pt[PC_L_PPPT];
-#pragma unroll
-            for (int j = 0; j < PC_L_PPPT; j++) pt[j] = g[min((uint32_t)(tid + j * PC_L_PTPB), cnt - 1)];
-            __syncthreads();
-            uint32_t tag[PC_L_PPPT];                   // cell | rank << 10, or ~0 for "skip"
-#pragma unroll
-            for (int j = 0; j < PC_L_PPPT; j++) {
-                tag[j] = 0xFFFFFFFFu;
-                if ((uint32_t)(tid + j * PC_L_PTPB) < cnt) {
-                    const uint32_t b = (uint32_t)pc_cell_index(pt[j].z, geo);
-                    if (b < (unsigned)geo.ncell) tag[j] = b | (atomicAdd(&hist[b], 1u) << 10);
-                }
-            }
-            __syncthreads();
-            if (tid < 64) {                            // exclusive scan of the tile's cell counts
-                uint32_t c[7], sum = 0;
-#pragma unroll
-                for (int q = 0; q < 7; q++) {
-                    const int b = tid * 7 + q;
-                    c[q] = b < PC_L_BINS ? hist[b] : 0u;
-                    sum += c[q];
-                }
-                uint32_t run = pc_wave_incl_scan(sum) - sum;
-#pragma unroll
-                for (int q = 0; q < 7; q++) {
-                    const int b = tid * 7 + q;
-                    if (b < PC_L_BINS) lstart[b] = run;
-                    run += c[q];
-                }
-            }
-            __syncthreads();
-            for (int b = tid; b < PC_L_BINS; b += PC_L_PTPB) {      // claim global space: one atomic per non-empty cell
-                const uint32_t c = hist[b];
-                if (c) delta[b] = atomicAdd(&cursor[b], c) - lstart[b];
-            }
-#pragma unroll
-            for (int j = 0; j < PC_L_PPPT; j++) {
-                if (tag[j] != 0xFFFFFFFFu) {
-                    const uint32_t b = tag[j] & 1023u, pos = lstart[b] + (tag[j] >> 10);
-                    buf[3 * pos] = pt[j].x;
-                    buf[3 * pos + 1] = pt[j].y;
-                    buf[3 * pos + 2] = pt[j].z;
-                    bin_of[pos] = (uint16_t)b;
-                }
-            }
-            __syncthreads();
-            const uint32_t kept = lstart[PC_L_BINS - 1] + hist[PC_L_BINS - 1];
-            for (uint32_t d = tid; d < 3 * kept; d += PC_L_PTPB) {   // runs -> global, coalesced dwords
-                const uint32_t e = d / 3u;
-                const uint32_t slot = delta[bin_of[e]] + e;
-                dst[3 * (uint64_t)slot + (d - 3u * e)] = buf[d];
-            }
-        }
-    }
 }
