@@ -236,6 +236,28 @@ def test_slab_shards_sum_to_whole(psa, stages, torch_mod, oracle):
         assert total == whole and tt == whole_tests
 
 
+def test_huge_pencils_inside_and_outside_a_slab(psa, stages, torch_mod, oracle):
+    """Pencils beyond a workgroup's sorting capacity, listed by the level-Y scan for the tile-parallel sort: a slab
+    call sorts only those of its own layers and its halo layer, whether the other layers' points are passed or not."""
+    import oracle_lib
+    rng = np.random.default_rng(61)
+    xyz = np.concatenate([_cell_box(rng, 30_000, (77, 200, 0), (78, 201, 400)),
+                          _cell_box(rng, 8_200, (78, 200, 0), (79, 201, 400)),
+                          _cell_box(rng, 12_000, (79, 201, 50), (80, 202, 350)),
+                          rng.uniform(-9.999, 9.999, (60_000, 3))]).astype(np.float32)
+    whole, whole_tests, _ = gpu_count(psa, stages, torch_mod, xyz)
+    assert whole == oracle.count_pairs(xyz)[0]
+    keys = oracle.cell_keys(xyz)
+    for cuts in ([0, 78, 400], [0, 77, 79, 80, 400]):
+        total = tt = total_all = 0
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            c, t, _ = gpu_count(psa, stages, torch_mod, oracle_lib.slab_points(xyz, keys, lo, hi), lo, hi)
+            total += c
+            tt += t
+            total_all += gpu_count(psa, stages, torch_mod, xyz, lo, hi)[0]       # every point passed, slab restricted
+        assert total == whole and tt == whole_tests and total_all == whole, cuts
+
+
 def test_streaming_interface_threads(psa, torch_mod, oracle):
     """pc_create / pc_append from several threads / pc_finish: the reference's seams."""
     import threading
