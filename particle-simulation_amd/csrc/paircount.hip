@@ -409,14 +409,11 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
     const uint32_t first_pencil = (uint32_t)layer_lo * PC_NBB, end_pencil = (uint32_t)(layer_hi + 1) * PC_NBB;
     const uint32_t l7_blocks = (end_pencil - first_pencil + PC_L7_WAVES - 1) / PC_L7_WAVES;
     const dim3 l7_grid(l7_blocks + PC_L7H_GRID);
-    if (sparse)
-        PC_LAUNCH("pc_l7_sort_pencils", pc_l7_sort_pencils<PC_L7_CAP_SPARSE>, l7_grid, dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted,
-                  w.pencil_start, table, first_pencil, end_pencil, d_status, t_geo, fgate, l7_blocks, w.big_count + 1, w.huge_list,
-                  w.huge_count);
-    else
-        PC_LAUNCH("pc_l7_sort_pencils", pc_l7_sort_pencils<PC_L7_CAP>, l7_grid, dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted,
-                  w.pencil_start, table, first_pencil, end_pencil, d_status, t_geo, fgate, l7_blocks, w.big_count + 1, w.huge_list,
-                  w.huge_count);
+    // (large inputs stream through L7 with non-temporal loads and stores: see PC_L_STREAM_POINTS)
+    auto l7 = sparse ? pc_l7_sort_pencils<PC_L7_CAP_SPARSE, false>
+                     : n > PC_L_STREAM_POINTS ? pc_l7_sort_pencils<PC_L7_CAP, true> : pc_l7_sort_pencils<PC_L7_CAP, false>;
+    PC_LAUNCH("pc_l7_sort_pencils", l7, l7_grid, dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted, w.pencil_start, table, first_pencil,
+              end_pencil, d_status, t_geo, fgate, l7_blocks, w.big_count + 1, w.huge_list, w.huge_count);
     auto small = pc_l7b_sort_big_pencils<PC_L7B_CAP_SMALL, PC_L7B_TPB_SMALL>;
     auto large = pc_l7b_sort_big_pencils<PC_L7B_CAP_LARGE, PC_L7B_TPB_LARGE>;
     const launch_sizes *sizes = nullptr;

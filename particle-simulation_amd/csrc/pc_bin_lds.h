@@ -38,6 +38,43 @@
 
 struct pc_pt3 { float x, y, z; };              // one point of the arrays: 12 bytes, 4-byte aligned
 
+// Streaming accesses.  A load or store can carry the non-temporal hint (the `nt` bit of the instruction).  What it
+// does to a kernel AND to the kernel after it (which finds more or less of its input in the 256 MB memory-side
+// cache) was measured at 100 M uniform points, kernel by kernel (profiles/r3e_cache_hints.txt):
+//   L1's loads          0.208 -> 0.190 ms, nothing else moves: always on
+//   L7's loads + stores 0.489 -> 0.478 ms at 100 M points, but 0.067 -> 0.074 ms on a 12.7 M-point slab, whose
+//                       arrays the cache holds whole: on for inputs above PC_L_STREAM_POINTS only (run time)
+//   partition loads     the kernel itself 1 % faster, the kernels after it 3-20 % slower: off
+//   partition stores    3.2x slower (the runs' partial lines no longer merge in the L2): off
+//   L4's loads, L7's table stores   slower: off
+// PC_L_NT switches them for measurements (bit 0: loads of the partition kernels, 1: their stores, 2: loads of L7,
+// 3: its stores, 4: loads of L1, 5: loads of level X's partition only, 6: of level Y's only, 7: loads of L4,
+// 8: L7's table stores); the product build has bit 4 set and gives L7 its hint at run time.
+#ifndef PC_L_NT
+#define PC_L_NT 16
+#endif
+#define PC_L_STREAM_POINTS 40000000ull         // L7 streams (nt loads and stores) above this many points
+typedef float pc_v3f_u __attribute__((ext_vector_type(3), aligned(4)));
+typedef float pc_v4f_a __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ pc_pt3 pc_load_pt(const pc_pt3 *p)
+{
+    if constexpr (NT) {
+        const pc_v3f_u v = __builtin_nontemporal_load(reinterpret_cast<const pc_v3f_u *>(p));
+        return pc_pt3{v.x, v.y, v.z};
+    } else
+        return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void pc_store_pt(pc_pt3 *p, const pc_pt3 &v)
+{
+    if constexpr (NT) {
+        const pc_v3f_u w = {v.x, v.y, v.z};
+        __builtin_nontemporal_store(w, reinterpret_cast<pc_v3f_u *>(p));
+    } else
+        *p = v;
+}
+
 #define PC_L_NREP 8                            // levels X and Y keep one cursor set per XCD group (tile % 8)
 #define PC_L_PSTRIDE (PC_L_NPENCILS + 7)        // pencil counters per replica (padded)
 
@@ -85,7 +122,8 @@ pc_l1_hist_x(const float *__restrict__ xyz, uint64_t n, uint32_t *__restrict__ l
         float xs[PC_L_PPT];
 #pragma unroll
         for (int j = 0; j < PC_L_PPT; j++)
-            xs[j] = xyz[3 * (first + min((uint32_t)(threadIdx.x + j * PC_L_TPB), cnt - 1))];
+            xs[j] = (PC_L_NT & 16) ? __builtin_nontemporal_load(xyz + 3 * (first + min((uint32_t)(threadIdx.x + j * PC_L_TPB), cnt - 1)))
+                                   : xyz[3 * (first + min((uint32_t)(threadIdx.x + j * PC_L_TPB), cnt - 1))];
 #pragma unroll
         for (int j = 0; j < PC_L_PPT; j++) {
             if ((uint32_t)(threadIdx.x + j * PC_L_TPB) < cnt) {
@@ -192,7 +230,8 @@ pc_l4_hist_y(const uint16_t *__restrict__ ycell, const uint32_t *__restrict__ la
     uint32_t ys[PC_L_PPT];
 #pragma unroll
     for (int j = 0; j < PC_L_PPT; j++)
-        ys[j] = ycell[(uint64_t)first + min((uint32_t)(threadIdx.x + j * PC_L_TPB), cnt - 1)];
+        ys[j] = (PC_L_NT & 128) ? __builtin_nontemporal_load(ycell + (uint64_t)first + min((uint32_t)(threadIdx.x + j * PC_L_TPB), cnt - 1))
+                                : ycell[(uint64_t)first + min((uint32_t)(threadIdx.x + j * PC_L_TPB), cnt - 1)];
     __syncthreads();
     bool bad = false;
 #pragma unroll
@@ -333,7 +372,7 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
     const pc_pt3 *g = reinterpret_cast<const pc_pt3 *>(src) + first;
     pc_pt3 pt[PPT];
 #pragma unroll
-    for (int j = 0; j < PPT; j++) pt[j] = g[min((uint32_t)(tid + j * TPB), cnt - 1)];
+    for (int j = 0; j < PPT; j++) pt[j] = pc_load_pt<(PC_L_NT & (LEVEL == 0 ? 1 | 32 : 1 | 64)) != 0>(g + min((uint32_t)(tid + j * TPB), cnt - 1));
 #ifdef PC_L_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -414,10 +453,12 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
 #else
         const uint32_t slot = delta[b] + e;
 #endif
-        reinterpret_cast<pc_pt3 *>(dst)[slot] = p;
+        pc_store_pt<(PC_L_NT & 2) != 0>(reinterpret_cast<pc_pt3 *>(dst) + slot, p);
         if (LEVEL == 0) {
             const int cy = pc_cell_index(p.y, geo);
-            ycell[slot] = (unsigned)cy < (unsigned)geo.ncell ? (uint16_t)cy : (uint16_t)0xFFFFu;
+            const uint16_t yc = (unsigned)cy < (unsigned)geo.ncell ? (uint16_t)cy : (uint16_t)0xFFFFu;
+            if (PC_L_NT & 2) __builtin_nontemporal_store(yc, ycell + slot);
+            else ycell[slot] = yc;
         }
     }
 #ifdef PC_L_TRACE
@@ -624,7 +665,7 @@ __device__ __forceinline__ void pc_l7h_partition_role(uint32_t blk, uint32_t nbl
     }
 }
 
-template <int CAP>
+template <int CAP, bool STREAM>
 __global__ void __launch_bounds__(PC_L7_WAVES * 64)
 pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
                    const uint32_t *__restrict__ pencil_start, uint32_t *__restrict__ table,
@@ -666,7 +707,7 @@ pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
         uint32_t tag[PPL];
 #pragma unroll
         for (int j = 0; j < PPL; j++)            // all loads first: one memory round trip
-            if (j < rounds) pt[j] = g[min(lane + 64u * j, n - 1)];
+            if (j < rounds) pt[j] = pc_load_pt<STREAM || (PC_L_NT & 4) != 0>(g + min(lane + 64u * j, n - 1));
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
             tag[j] = 0xFFFFFFFFu;
@@ -679,7 +720,10 @@ pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
         pc_wave_lds_sync();
         pc_l7_scan_bins(hist, lane);                   // hist now holds the exclusive starts
         pc_wave_lds_sync();
-        for (int k = lane; k < PC_NBB; k += 64) slice[k] = base + hist[k];
+        for (int k = lane; k < PC_NBB; k += 64) {
+            if (PC_L_NT & 256) __builtin_nontemporal_store(base + hist[k], slice + k);
+            else slice[k] = base + hist[k];
+        }
         // The pencil in cell order goes through LDS and leaves as 16-byte stores.
         // `shift` gives the staged copy the same position modulo 16 bytes as its
         // destination, so every aligned 16-byte LDS read feeds an aligned global store.
@@ -701,8 +745,13 @@ pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
         const uint32_t head = min((4u - shift) & 3u, nd);          // dwords before the first 16-byte boundary
         const uint32_t nbody = (nd - head) >> 2;
         if ((uint32_t)lane < head) od[lane] = stage[shift + lane];
-        for (uint32_t q = lane; q < nbody; q += 64)
-            *reinterpret_cast<float4 *>(od + head + 4u * q) = *reinterpret_cast<const float4 *>(stage + shift + head + 4u * q);
+        for (uint32_t q = lane; q < nbody; q += 64) {
+            if (STREAM || (PC_L_NT & 8))
+                __builtin_nontemporal_store(*reinterpret_cast<const pc_v4f_a *>(stage + shift + head + 4u * q),
+                                            reinterpret_cast<pc_v4f_a *>(od + head + 4u * q));
+            else
+                *reinterpret_cast<float4 *>(od + head + 4u * q) = *reinterpret_cast<const float4 *>(stage + shift + head + 4u * q);
+        }
         const uint32_t t0 = head + 4u * nbody;
         if ((uint32_t)lane < nd - t0) od[t0 + lane] = stage[shift + t0 + lane];
     }
