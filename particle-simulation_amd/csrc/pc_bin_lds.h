@@ -54,6 +54,17 @@ struct pc_pt3 { float x, y, z; };              // one point of the arrays: 12 by
 #define PC_L_NT 16
 #endif
 #define PC_L_STREAM_POINTS 40000000ull         // L7 streams (nt loads and stores) above this many points
+
+// Direction in which a kernel walks its input.  A kernel that starts where the kernel before it stopped writing
+// finds those lines in the memory-side cache: L7 takes the pencils from the last to the first, because level Y's
+// partition wrote the last layers last (0.476 -> 0.464 ms at 100 M points).  Measured and left alone
+// (profiles/r3e_cache_hints.txt): level Y's partition, L4 and the merged-window pair test backwards (no gain),
+// level X's partition backwards behind an L1 without the non-temporal hint (L1 loses more than L3 gains).
+// PC_L_REV, a bit per kernel, for measurements: 1 level Y's partition, 2 L7, 4 the merged-window pair test,
+// 8 level X's partition, 16 L4.
+#ifndef PC_L_REV
+#define PC_L_REV 2
+#endif
 typedef float pc_v3f_u __attribute__((ext_vector_type(3), aligned(4)));
 typedef float pc_v4f_a __attribute__((ext_vector_type(4)));
 template <bool NT>
@@ -222,8 +233,9 @@ pc_l4_hist_y(const uint16_t *__restrict__ ycell, const uint32_t *__restrict__ la
 {
     __shared__ uint32_t h[PC_L_BINS];
     if (blockIdx.x >= layer_tile[PC_NBB]) return;
-    const int layer = (int)tile_layer[blockIdx.x];
-    const uint32_t chunk = blockIdx.x - layer_tile[layer];
+    const uint32_t tile = (PC_L_REV & 16) ? layer_tile[PC_NBB] - 1u - blockIdx.x : blockIdx.x;
+    const int layer = (int)tile_layer[tile];
+    const uint32_t chunk = tile - layer_tile[layer];
     const uint32_t first = layer_start[layer] + chunk * PC_L_TILE;
     const uint32_t cnt = min((uint32_t)PC_L_TILE, layer_start[layer + 1] - first);
     for (int b = threadIdx.x; b < PC_L_BINS; b += PC_L_TPB) h[b] = 0;
@@ -243,7 +255,7 @@ pc_l4_hist_y(const uint16_t *__restrict__ ycell, const uint32_t *__restrict__ la
     }
     __syncthreads();
     for (int b = threadIdx.x; b < 400; b += PC_L_TPB)
-        if (h[b]) atomicAdd(&pencil_count[(blockIdx.x % PC_L_NREP) * PC_L_PSTRIDE + layer * PC_NBB + b], h[b]);
+        if (h[b]) atomicAdd(&pencil_count[(tile % PC_L_NREP) * PC_L_PSTRIDE + layer * PC_NBB + b], h[b]);
     if (bad) atomicOr(status, 1);
 }
 
@@ -351,17 +363,19 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
     uint64_t first;
     uint32_t cnt;
     if (LEVEL == 0) {
-        first = (uint64_t)blockIdx.x * PC_L_TILE;
+        const uint32_t tile = (PC_L_REV & 8) ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+        first = (uint64_t)tile * PC_L_TILE;
         if (first >= n) return;
         cnt = (uint32_t)min((uint64_t)PC_L_TILE, n - first);
-        cursor += (blockIdx.x % PC_L_NREP) * PC_L_BINS;       // this tile's replica (see L1)
+        cursor += (tile % PC_L_NREP) * PC_L_BINS;             // this tile's replica (see L1)
     } else {
         if (blockIdx.x >= layer_tile[PC_NBB]) return;
-        const int layer = (int)tile_layer[blockIdx.x];
-        const uint32_t chunk = blockIdx.x - layer_tile[layer];
+        const uint32_t tile = (PC_L_REV & 1) ? layer_tile[PC_NBB] - 1u - blockIdx.x : blockIdx.x;
+        const int layer = (int)tile_layer[tile];
+        const uint32_t chunk = tile - layer_tile[layer];
         first = (uint64_t)layer_start[layer] + (uint64_t)chunk * PC_L_TILE;
         cnt = min((uint32_t)PC_L_TILE, layer_start[layer + 1] - (uint32_t)first);
-        cursor += (blockIdx.x % PC_L_NREP) * PC_L_PSTRIDE + layer * PC_NBB;
+        cursor += (tile % PC_L_NREP) * PC_L_PSTRIDE + layer * PC_NBB;
     }
 #ifdef PC_L_TRACE
     unsigned long long mark_ = __builtin_readcyclecounter(), spent_[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -685,8 +699,8 @@ pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t *hist = hist_all[wave];
     // pencils [first_pencil, end_pencil): all of them, or the layers one slab's pair test reads
-    const uint32_t pencil = first_pencil + blockIdx.x * PC_L7_WAVES + wave;
-    if (pencil >= end_pencil) return;
+    const uint32_t pencil = (PC_L_REV & 2) ? end_pencil - 1u - (blockIdx.x * PC_L7_WAVES + wave) : first_pencil + blockIdx.x * PC_L7_WAVES + wave;
+    if (pencil >= end_pencil || pencil < first_pencil) return;
     const uint32_t base = pencil_start[pencil], n = pencil_start[pencil + 1] - base;
     uint32_t *slice = table + (uint64_t)pencil * PC_NBB;
     if (pencil == PC_L_NPENCILS - 1 && lane < 2) table[(uint64_t)PC_L_NPENCILS * PC_NBB + lane] = base + n;

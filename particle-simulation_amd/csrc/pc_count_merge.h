@@ -50,6 +50,9 @@
 #include "pc_count_global.h"
 #include "pc_count_group.h"
 
+#ifndef PC_L_REV
+#define PC_L_REV 2                      // (direction switches for measurements: see pc_bin_lds.h)
+#endif
 #ifndef PC_M_CAP
 #define PC_M_CAP 376                    // slots of a window's blocks (even)
 #endif
@@ -249,7 +252,7 @@ pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T
         if (m >= band_pencils) break;
         int m_next = 0;
         if (lane == 0) m_next = (int)atomicAdd(queue + g * PC_G_QUEUE_STRIDE, 1u);   // (its latency hides behind the pencil)
-        const int layer = x_lo + m / PC_G_BAND, j = g * PC_G_BAND + m % PC_G_BAND;
+        const int layer = (PC_L_REV & 4) ? x_hi - 1 - m / PC_G_BAND : x_lo + m / PC_G_BAND, j = g * PC_G_BAND + m % PC_G_BAND;
         const uint32_t pencil = (uint32_t)layer * PC_NBB + j;
         const uint32_t skip = planned[pencil];            // cut into segments by the planning kernel: variant 3's kernel takes it
 
