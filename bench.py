@@ -170,6 +170,8 @@ def main():
                          "stream produced on the GPU bit for bit (faster set-up at 1 B points)")
     ap.add_argument("--bin-variant", type=int, default=None)
     ap.add_argument("--count-variant", type=int, default=None)
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
+                    help="any other knob of pc_set_variant (measurements), e.g. --set split=1")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks "
                          "(ranks share devices, the 8-byte sum goes through host memory)")
@@ -243,6 +245,9 @@ def main():
         psa.set_variant("bin", args.bin_variant)
     if args.count_variant is not None:
         psa.set_variant("count", args.count_variant)
+    for kv in args.set:
+        name, _, value = kv.partition("=")
+        psa.set_variant(name, int(value))
 
     # ---- synthetic input: this rank's slab plus its +x halo layer, resident in HBM ----
     t_gen = time.time()
