@@ -25,7 +25,10 @@
 #ifndef PC_L_PPT
 #define PC_L_PPT 16
 #endif
-#define PC_L_TILE (PC_L_TPB * PC_L_PPT)        // 4096 points = 48 KB of LDS
+#define PC_L_TILE (PC_L_TPB * PC_L_PPT)        // points of a tile
+#define PC_L_LDS_POINTS 4096                   // points of a tile that the partition kernels hold in LDS at a time: 48 KB
+#define PC_L7H_TILE 4096                       // tile of the tile-parallel sort of huge pencils (L7H)
+static_assert(PC_L_TILE % PC_L_LDS_POINTS == 0, "a tile is written out in whole passes of PC_L_LDS_POINTS points");
 #ifndef PC_L_PTPB
 #define PC_L_PTPB 512                          // partition kernels: threads per tile (level Y and the huge pencils) ...
 #endif
@@ -353,8 +356,9 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
                  const uint32_t *__restrict__ tile_layer, uint32_t *__restrict__ cursor, uint16_t *__restrict__ ycell, const pc_geom geo)
 {
     constexpr int TPB = LEVEL == 0 ? PC_L_XTPB : PC_L_PTPB, PPT = PC_L_TILE / TPB;
-    __shared__ float buf[PC_L_TILE * 3];              // the tile sorted by bin: 48 KB, with the three small arrays 54 000 bytes,
-                                                      // so that three workgroups share a CU's 160 KB
+    __shared__ float buf[PC_L_LDS_POINTS * 3];        // a tile's points in bin order, PC_L_LDS_POINTS at a time: 48 KB, with the
+                                                      // three small arrays 54 000 bytes, so that three workgroups share a CU's 160 KB
+    constexpr int PASSES = PC_L_TILE / PC_L_LDS_POINTS;
     __shared__ uint32_t hist[PC_L_BINS];
     __shared__ uint32_t lstart[PC_L_BINS];
     __shared__ uint32_t delta[PC_L_BINS];             // global slot of bin's first point minus lstart
@@ -435,44 +439,56 @@ pc_l36_partition(const float *__restrict__ src, uint64_t n, float *__restrict__ 
         claimed[q] = 0;
         if (b < PC_L_BINS && hist[b]) claimed[q] = atomicAdd(&cursor[b], hist[b]);
     }
-    // the tile in bin order -> LDS
+    // The tile in bin order -> LDS -> global.  A tile larger than the LDS buffer goes in passes: pass q takes the
+    // points whose place in the tile's bin order is [q, q + 1) * PC_L_LDS_POINTS (they wait in registers until then),
+    // so a bin's run in global memory is as long as the whole tile makes it, not as long as the buffer would.
 #pragma unroll
-    for (int j = 0; j < PPT; j++) {
-        if (tag[j] != 0xFFFFFFFFu) {
-            const uint32_t b = tag[j] & 1023u, pos = lstart[b] + (tag[j] >> 10);
-            buf[3 * pos] = pt[j].x;
-            buf[3 * pos + 1] = pt[j].y;
-            buf[3 * pos + 2] = pt[j].z;
+    for (int pass = 0; pass < PASSES; pass++) {
+        const uint32_t base = (uint32_t)pass * PC_L_LDS_POINTS;
+        if (pass > 0) __syncthreads();                 // the previous pass's reads of buf are done
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+            if (tag[j] != 0xFFFFFFFFu) {
+                const uint32_t b = tag[j] & 1023u, pos = lstart[b] + (tag[j] >> 10) - base;
+                if (PASSES == 1 || pos < PC_L_LDS_POINTS) {   // (unsigned: also false below the pass's range)
+                    buf[3 * pos] = pt[j].x;
+                    buf[3 * pos + 1] = pt[j].y;
+                    buf[3 * pos + 2] = pt[j].z;
+                }
+            }
         }
-    }
+        if (pass == 0) {
 #pragma unroll
-    for (int q = 0; q < CLAIMS; q++) {
-        const int b = tid + q * TPB;
-        if (b < PC_L_BINS) delta[b] = claimed[q] - lstart[b];
-    }
+            for (int q = 0; q < CLAIMS; q++) {
+                const int b = tid + q * TPB;
+                if (b < PC_L_BINS) delta[b] = claimed[q] - lstart[b];
+            }
 #ifdef PC_L_TRACE
-    PC_L_MARK(3);                                      // tile scattered into LDS (this thread's share), claims issued
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            PC_L_MARK(3);                              // tile scattered into LDS (this thread's share), claims issued
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
-    __syncthreads();
-    PC_L_MARK(4);                                      // claims answered, LDS complete
-    const uint32_t kept = lstart[PC_L_BINS - 1] + hist[PC_L_BINS - 1];
-    // runs -> global, a point per lane (12-byte stores, consecutive lanes on consecutive slots of a run); the bin
-    // is computed again from the coordinate, which leaves the LDS to the points alone
-    for (uint32_t e = tid; e < kept; e += TPB) {
-        const pc_pt3 p = {buf[3 * e], buf[3 * e + 1], buf[3 * e + 2]};
-        const uint32_t b = (uint32_t)pc_cell_index(LEVEL == 0 ? p.x : p.y, geo);
+        }
+        __syncthreads();
+        if (pass == 0) PC_L_MARK(4);                   // claims answered, LDS complete
+        const uint32_t kept = lstart[PC_L_BINS - 1] + hist[PC_L_BINS - 1];
+        const uint32_t here = kept > base ? min(kept - base, (uint32_t)PC_L_LDS_POINTS) : 0u;
+        // runs -> global, a point per lane (12-byte stores, consecutive lanes on consecutive slots of a run); the bin
+        // is computed again from the coordinate, which leaves the LDS to the points alone
+        for (uint32_t e = tid; e < here; e += TPB) {
+            const pc_pt3 p = {buf[3 * e], buf[3 * e + 1], buf[3 * e + 2]};
+            const uint32_t b = (uint32_t)pc_cell_index(LEVEL == 0 ? p.x : p.y, geo);
 #ifdef PC_L_EXP_LINEAR                                 // measurement build: the tile goes back where it came from, as one contiguous run
-        const uint32_t slot = (uint32_t)first + e + 0u * delta[b];
+            const uint32_t slot = (uint32_t)first + base + e + 0u * delta[b];
 #else
-        const uint32_t slot = delta[b] + e;
+            const uint32_t slot = delta[b] + base + e;
 #endif
-        pc_store_pt<(PC_L_NT & 2) != 0>(reinterpret_cast<pc_pt3 *>(dst) + slot, p);
-        if (LEVEL == 0) {
-            const int cy = pc_cell_index(p.y, geo);
-            const uint16_t yc = (unsigned)cy < (unsigned)geo.ncell ? (uint16_t)cy : (uint16_t)0xFFFFu;
-            if (PC_L_NT & 2) __builtin_nontemporal_store(yc, ycell + slot);
-            else ycell[slot] = yc;
+            pc_store_pt<(PC_L_NT & 2) != 0>(reinterpret_cast<pc_pt3 *>(dst) + slot, p);
+            if (LEVEL == 0) {
+                const int cy = pc_cell_index(p.y, geo);
+                const uint16_t yc = (unsigned)cy < (unsigned)geo.ncell ? (uint16_t)cy : (uint16_t)0xFFFFu;
+                if (PC_L_NT & 2) __builtin_nontemporal_store(yc, ycell + slot);
+                else ycell[slot] = yc;
+            }
         }
     }
 #ifdef PC_L_TRACE
@@ -529,6 +545,7 @@ __device__ __forceinline__ void pc_l7_scan_bins(uint32_t *hist, int lane)
 // and in the order the steps need: the histogram with L7, the scan with the small L7B
 // instantiation, the partition with the large one.  A role's workgroups are numbered
 // blk = 0 .. nblk-1.
+#define PC_L7H_PPPT (PC_L7H_TILE / PC_L_PTPB)          // points per thread of the partition role
 #define PC_L7H_GRID 1024                               // workgroups of the histogram and of the partition role
 #define PC_L7H_SCAN_GRID 64                            // and of the scan role (one wave of each works)
 __device__ __forceinline__ uint32_t pc_l7h_first_tile(uint32_t h, uint32_t blk, uint32_t nblk)
@@ -545,17 +562,17 @@ __device__ __forceinline__ void pc_l7h_hist_role(uint32_t blk, uint32_t nblk, ui
 {
     const uint32_t entries = *huge_n;
     if (entries == 0) return;
-    constexpr int BATCH = 8, PPT = PC_L_TILE / TPB;
+    constexpr int BATCH = 8, PPT = PC_L7H_TILE / TPB;
     static_assert(PPT % BATCH == 0, "tile / threads must be a multiple of the load batch");
     const int tid = threadIdx.x;
     bool bad = false;
     for (uint32_t h = 0; h < entries; h++) {
         const uint32_t pencil = huge_list[h];
         const uint32_t base = pencil_start[pencil], n = pencil_start[pencil + 1] - base;
-        const uint32_t ntiles = (n + PC_L_TILE - 1) / PC_L_TILE;
+        const uint32_t ntiles = (n + PC_L7H_TILE - 1) / PC_L7H_TILE;
         const pc_pt3 *g = reinterpret_cast<const pc_pt3 *>(src) + base;
         for (uint32_t t = pc_l7h_first_tile(h, blk, nblk); t < ntiles; t += nblk) {
-            const uint32_t first = t * PC_L_TILE, cnt = min((uint32_t)PC_L_TILE, n - first);
+            const uint32_t first = t * PC_L7H_TILE, cnt = min((uint32_t)PC_L7H_TILE, n - first);
             __syncthreads();
             for (int b = tid; b < PC_L_BINS; b += TPB) h_lds[b] = 0;
             __syncthreads();
@@ -603,7 +620,7 @@ __device__ __forceinline__ void pc_l7h_scan_role(uint32_t blk, uint32_t nblk, ui
     }
 }
 
-// partition role: PC_L_PTPB threads; LDS: buf = a tile of points (PC_L_TILE * 3 floats), bin_of (PC_L_TILE), three
+// partition role: PC_L_PTPB threads; LDS: buf = a tile of points (PC_L7H_TILE * 3 floats), bin_of (PC_L7H_TILE), three
 // arrays of PC_L_BINS words
 __device__ __forceinline__ void pc_l7h_partition_role(uint32_t blk, uint32_t nblk, float *buf, uint16_t *bin_of, uint32_t *hist,
                                                       uint32_t *lstart, uint32_t *delta, const float *__restrict__ src,
@@ -616,20 +633,20 @@ __device__ __forceinline__ void pc_l7h_partition_role(uint32_t blk, uint32_t nbl
     for (uint32_t h = 0; h < entries; h++) {
         const uint32_t pencil = huge_list[h];
         const uint32_t base = pencil_start[pencil], n = pencil_start[pencil + 1] - base;
-        const uint32_t ntiles = (n + PC_L_TILE - 1) / PC_L_TILE;
+        const uint32_t ntiles = (n + PC_L7H_TILE - 1) / PC_L7H_TILE;
         uint32_t *cursor = huge_cursor + (uint64_t)h * PC_L_BINS;
         for (uint32_t t = pc_l7h_first_tile(h, blk, nblk); t < ntiles; t += nblk) {
-            const uint32_t first = t * PC_L_TILE, cnt = min((uint32_t)PC_L_TILE, n - first);
+            const uint32_t first = t * PC_L7H_TILE, cnt = min((uint32_t)PC_L7H_TILE, n - first);
             const pc_pt3 *g = reinterpret_cast<const pc_pt3 *>(src) + base + first;
             __syncthreads();                           // the previous tile's LDS reads are done
             for (int b = tid; b < PC_L_BINS; b += PC_L_PTPB) hist[b] = 0;
-            pc_pt3 pt[PC_L_PPPT];
+            pc_pt3 pt[PC_L7H_PPPT];
 #pragma unroll
-            for (int j = 0; j < PC_L_PPPT; j++) pt[j] = g[min((uint32_t)(tid + j * PC_L_PTPB), cnt - 1)];
+            for (int j = 0; j < PC_L7H_PPPT; j++) pt[j] = g[min((uint32_t)(tid + j * PC_L_PTPB), cnt - 1)];
             __syncthreads();
-            uint32_t tag[PC_L_PPPT];                   // cell | rank << 10, or ~0 for "skip"
+            uint32_t tag[PC_L7H_PPPT];                   // cell | rank << 10, or ~0 for "skip"
 #pragma unroll
-            for (int j = 0; j < PC_L_PPPT; j++) {
+            for (int j = 0; j < PC_L7H_PPPT; j++) {
                 tag[j] = 0xFFFFFFFFu;
                 if ((uint32_t)(tid + j * PC_L_PTPB) < cnt) {
                     const uint32_t b = (uint32_t)pc_cell_index(pt[j].z, geo);
@@ -659,7 +676,7 @@ __device__ __forceinline__ void pc_l7h_partition_role(uint32_t blk, uint32_t nbl
                 if (c) delta[b] = atomicAdd(&cursor[b], c) - lstart[b];
             }
 #pragma unroll
-            for (int j = 0; j < PC_L_PPPT; j++) {
+            for (int j = 0; j < PC_L7H_PPPT; j++) {
                 if (tag[j] != 0xFFFFFFFFu) {
                     const uint32_t b = tag[j] & 1023u, pos = lstart[b] + (tag[j] >> 10);
                     buf[3 * pos] = pt[j].x;
@@ -806,9 +823,9 @@ pc_l7b_sort_big_pencils(const float *__restrict__ src, float *__restrict__ dst,
         else {
             static_assert(PC_L7B_CAP == PC_L7B_CAP_SMALL || PC_L7B_TPB == PC_L_PTPB, "the partition role runs with PC_L_PTPB threads");
             static_assert(PC_L7B_CAP == PC_L7B_CAP_SMALL ||
-                          PC_L7B_CAP * 3 >= PC_L_TILE * 3 + PC_L_TILE / 2 + 2 * PC_L_BINS, "the partition role's arrays lie inside `stage`");
-            uint32_t *words = reinterpret_cast<uint32_t *>(stage + PC_L_TILE * 3 + PC_L_TILE / 2);
-            pc_l7h_partition_role(blk, nblk, stage, reinterpret_cast<uint16_t *>(stage + PC_L_TILE * 3), hist, words, words + PC_L_BINS,
+                          PC_L7B_CAP * 3 >= PC_L7H_TILE * 3 + PC_L7H_TILE / 2 + 2 * PC_L_BINS, "the partition role's arrays lie inside `stage`");
+            uint32_t *words = reinterpret_cast<uint32_t *>(stage + PC_L7H_TILE * 3 + PC_L7H_TILE / 2);
+            pc_l7h_partition_role(blk, nblk, stage, reinterpret_cast<uint16_t *>(stage + PC_L7H_TILE * 3), hist, words, words + PC_L_BINS,
                                   src, dst, pencil_start, huge_n, huge_list, huge_cursor, geo);
         }
         return;
