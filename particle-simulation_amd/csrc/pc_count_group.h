@@ -61,11 +61,17 @@
 #define PC_GATE_ALWAYS 0
 #define PC_GATE_IF_EVEN 1            // run only if the dense points are at most the limit
 #define PC_GATE_IF_CLUSTERED 2       // run only if they are more
+// set by the planning kernel when its segments do not fit the list (an input so heavy that more than PC_G_SEG_CAP
+// segments are wanted, e.g. 10^9 points on one GPU): the kernels then divide the work as for a clustered input, whose
+// group kernel takes uncut pencils whole; the merged-window kernel would find the list full for what it defers and
+// count those pencils a home particle per lane
+#define PC_G_SEG_OVERFLOW 290
 __device__ __forceinline__ bool pc_gate_open(const unsigned int *queue, int gate, uint32_t limit)
 {
     if (__builtin_amdgcn_readfirstlane(queue[PC_G_SERVED]) != 0) return false;
     if (gate == PC_GATE_ALWAYS) return true;
-    const bool clustered = __builtin_amdgcn_readfirstlane(queue[PC_G_DENSE_POINTS]) > limit;
+    const bool clustered = __builtin_amdgcn_readfirstlane(queue[PC_G_DENSE_POINTS]) > limit ||
+                           __builtin_amdgcn_readfirstlane(queue[PC_G_SEG_OVERFLOW]) != 0;
     return (gate == PC_GATE_IF_CLUSTERED) == clustered;
 }
 #define PC_G_HEAVY (PC_G_SEGS + 2 * PC_G_SEG_CAP)
@@ -412,6 +418,7 @@ pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__r
         if (t < n_pencils)
             reinterpret_cast<unsigned char *>(work + PC_G_FLAGS)[(uint32_t)(x_lo + t / PC_NLAYERS) * PC_NBB + t % PC_NLAYERS] =
                 mine && at + mine <= seg_cap;
+        if (seg_cap != 0 && __builtin_amdgcn_ballot_w64(mine && at + mine > seg_cap) != 0 && lane == 0) work[PC_G_SEG_OVERFLOW] = 1u;
     }
     __syncthreads();
     for (int q = 0; q < per_wave; q++) {
