@@ -124,7 +124,7 @@ static std::atomic<int> g_variant_bin{1};     // 0 = atomic counting sort, 1 = L
 // 5 = merged single-run windows (variant 3's kernel for heavy pencils and what 5 defers),
 // 7 = level Z fused into the pair test (whole-path entry points only; the z sort and variant 4's choice take
 //     over, decided on the device, when a pencil neighbourhood exceeds the fused kernel's capacity),
-// 4 = by density: 0 below 2/3 of a point per cell of the slab on average, else 5
+// 4 = by density: 0 below 2/3 of a point per cell of the slab on average, 3 from 6 to 11 points per cell, else 5
 static std::atomic<int> g_variant_count{4};
 static std::atomic<int> g_heavy{PC_G_HEAVY_CAP};    // capacity of the list of over-full cells' home-particle chunks (0: never listed)
 static std::atomic<int> g_segments{PC_G_SEG_CAP};  // capacity of the heavy-pencil segment list (0: pencils are never cut)
@@ -640,8 +640,11 @@ static int count_sorted(const float *d_sorted_xyz, const uint32_t *d_cell_start,
     if (variant == 4) {
         // Sparse inputs: a window of cells holds too few particles to pay for its bookkeeping, and the
         // thread-per-particle kernel wins (measured crossover at 42 M uniform points = 0.66 per cell).
+        // Between 6 and 11 points per cell the group kernel takes the whole job: the merged-window kernel's runs get
+        // too long there, and the dense kernel, which works its pencils' segments off instead, pays only from about
+        // 11 points per cell (measured on a slab at 3 to 16 points per cell: up to 35 % at 7.8).
         const uint64_t cells = (uint64_t)(x_hi < PC_NLAYERS ? x_hi - x_lo + 1 : x_hi - x_lo) * PC_NLAYERS * PC_NLAYERS;
-        variant = n * 3 < cells * 2 ? 0 : 5;
+        variant = n * 3 < cells * 2 ? 0 : (n >= cells * 6 && n < cells * 11) ? 3 : 5;
     }
     if (variant == 0) {
         uint32_t c_lo = (uint32_t)x_lo * PC_NBB2, c_hi = (uint32_t)x_hi * PC_NBB2;

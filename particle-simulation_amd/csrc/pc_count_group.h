@@ -46,7 +46,9 @@
 #define PC_G_FLAGS 320
 #define PC_G_FLAG_WORDS ((PC_NBB * PC_NBB + 3) / 4 + 3)
 #define PC_G_SEGS (PC_G_FLAGS + PC_G_FLAG_WORDS)
+#ifndef PC_G_SEG_CAP
 #define PC_G_SEG_CAP 262144
+#endif
 // A single cell so full that its pairs are too much for one wave (many points in one
 // place) is not processed by the wave that meets it: its home particles go, 256 at a
 // time, on a list that a follow-up kernel (pc_c3_heavy, thread per home particle)
