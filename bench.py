@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--workload", default="uniform100m", choices=sorted(WORKLOADS))
     ap.add_argument("--points", type=int, default=0, help="override the workload's point count")
     ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--sigma-micro", type=int, default=None,
+                    help="clustered workloads: another blob width than the workload's, in millionths (measurements)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--generate", default="host", choices=["host", "device"],
                     help="where the synthetic points are made: the host generator (then copied), or the same "
@@ -224,6 +226,8 @@ def main():
     red_device = device if args.backend == "nccl" else torch.device("cpu")
 
     kind_name, base_points, sigma, scaling = WORKLOADS[args.workload]
+    if args.sigma_micro is not None:
+        sigma = args.sigma_micro
     total_points = args.points or (base_points * world if scaling == "weak" else base_points)
     kind = ht.UNIFORM if kind_name == "uniform" else ht.BLOBS
     sh = importlib.import_module("particle_simulation_amd.sharding")

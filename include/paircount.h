@@ -274,8 +274,11 @@ int pc_count_pairs_noalloc(const float *d_xyz, uint64_t n, int x_lo, int x_hi,
    maximum 262144; 0 = never cut a pencil), or "heavy": the capacity of its list
    of over-full cells' home-particle chunks (default and maximum 65536; 0 = such
    cells are processed by the wave that meets them), or "dense": which kernel works
-   the segment list off after the merged-window pair test (1, the default: the
-   candidates-in-registers kernel; 0: the group kernel), or "even": whether the
+   the segment list off after the merged-window pair test (1, the default: decided
+   per call on the device -- the candidates-in-registers kernel if most of the
+   listed points lie in segments with at least "dense_min" (default 11) points per
+   cell, else the group kernel; 0: the group kernel; 2: the candidates-in-registers
+   kernel), or "even": whether the
    merged-window pair test's grid is cut down to a whole number of pencils per wave
    (1, the default; 0: as many waves as are resident).  Returns PC_ERR_ARG for an
    unknown name or value. */

@@ -129,7 +129,8 @@ static std::atomic<int> g_variant_count{4};
 static std::atomic<int> g_heavy{PC_G_HEAVY_CAP};    // capacity of the list of over-full cells' home-particle chunks (0: never listed)
 static std::atomic<int> g_segments{PC_G_SEG_CAP};  // capacity of the heavy-pencil segment list (0: pencils are never cut)
 static std::atomic<int> g_even{1};                 // 1 = the merged-window kernel's grid is cut down to a whole number of pencils per wave
-static std::atomic<int> g_dense{1};                // who works the segment list off after the merged-window kernel: 1 = the dense kernel (variant 6), 0 = variant 3's
+static std::atomic<int> g_dense_min{PC_DENSE_MIN_DEFAULT};   // points per cell from which a listed segment counts as well filled
+static std::atomic<int> g_dense{1};                // who works the segment list off after the merged-window kernel: 1 = decided on the device from the list (dense kernel or variant 3's), 0 = variant 3's, 2 = the dense kernel
 
 // A context may carry its own choice of the two algorithm variants (pc_context_set_variant); while its pc_finish
 // runs, the calling thread sees that choice instead of the process-wide one (-1: not overridden).
@@ -182,8 +183,13 @@ extern "C" int pc_set_variant(const char *name, int value)
         g_even = value;
         return PC_OK;
     }
+    if (!strcmp(name, "dense_min")) {
+        if (value < 1 || value > 65535) return pc_fail(PC_ERR_ARG, "pc_set_variant: dense_min %d not in [1,65535]", value);
+        g_dense_min = value;
+        return PC_OK;
+    }
     if (!strcmp(name, "dense")) {
-        if (value < 0 || value > 1) return pc_fail(PC_ERR_ARG, "pc_set_variant: dense %d not 0 or 1", value);
+        if (value < 0 || value > 2) return pc_fail(PC_ERR_ARG, "pc_set_variant: dense %d not 0, 1 or 2", value);
         g_dense = value;
         return PC_OK;
     }
@@ -666,8 +672,11 @@ static int count_sorted(const float *d_sorted_xyz, const uint32_t *d_cell_start,
         const uint64_t full = 4 * n / slab_pencils;
         const uint32_t full_pencil = (uint32_t)(full < 512 ? 512 : full > 0xFFFFFFFFull ? 0xFFFFFFFFull : full);
         const uint32_t gate_limit = (uint32_t)(n / 4);
+        // dense = 1: the listed points are added up by kind, and the kernel that suits the majority takes the list
+        const int dense_mode = g_dense.load();
+        const uint32_t dense_min = variant == 5 && dense_mode == 1 ? (uint32_t)g_dense_min.load() : 0u;
         PC_LAUNCH("pc_c3_plan", pc_c3_plan, plan_grid, dim3(PC_G_PLAN_TPB), (hipStream_t)stream, d_cell_start, x_lo, x_hi, queue,
-                  seg_cap, full_pencil, fgate);
+                  seg_cap, full_pencil, fgate, dense_min);
         const launch_sizes *sizes = nullptr;
         rc2 = launch_sizes_of_current_device(&sizes);
         if (rc2) return rc2;
@@ -689,27 +698,29 @@ static int count_sorted(const float *d_sorted_xyz, const uint32_t *d_cell_start,
             grid5 = (grid5 + 7) / 8 * 8;
             PC_LAUNCH("pc_c5_count_merged", pc_c5_count_merged, dim3(grid5), dim3(64), (hipStream_t)stream,
                       d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, PC_GATE_IF_EVEN, gate_limit,
-                      (unsigned long long *)d_npairs, t_geo);
+                      (unsigned long long *)d_npairs, t_geo, dense_min);
         }
         const int grid = ((want < most ? want : most) + 7) / 8 * 8;
         if (variant == 5) {
-            if (g_dense.load()) {
-                // planned segments and pencil rests: cells filled well enough for the candidates-in-registers form
+            // planned segments and pencil rests: to the candidates-in-registers kernel if most of their points lie in
+            // well-filled cells, else to the group kernel (one of the two launches returns at once)
+            if (dense_mode != 0) {
                 const int r6 = sizes->c6;
                 PC_LAUNCH("pc_c6_count_dense", pc_c6_count_dense, dim3(r6), dim3(64), (hipStream_t)stream,
                           d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap, PC_GATE_IF_EVEN, gate_limit,
-                          (unsigned long long *)d_npairs, t_geo.d2max);
-            } else
+                          (unsigned long long *)d_npairs, t_geo.d2max, dense_min);
+            }
+            if (dense_mode != 2)
                 PC_LAUNCH("pc_c3_count_groups_segments", pc_c3_count_groups<false>, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
                           d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap, PC_GATE_IF_EVEN, gate_limit,
-                          (unsigned long long *)d_npairs, t_geo.d2max);
+                          (unsigned long long *)d_npairs, t_geo.d2max, dense_min);
             PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups<true>, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
                       d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap, PC_GATE_IF_CLUSTERED, gate_limit,
-                      (unsigned long long *)d_npairs, t_geo.d2max);
+                      (unsigned long long *)d_npairs, t_geo.d2max, 0u);
         } else
             PC_LAUNCH("pc_c3_count_groups", pc_c3_count_groups<true>, dim3(grid), dim3(PC_G_WAVES * 64), (hipStream_t)stream,
                       d_sorted_xyz, d_cell_start, x_lo, x_hi, queue, seg_cap, heavy_cap, PC_GATE_ALWAYS, 0u,
-                      (unsigned long long *)d_npairs, t_geo.d2max);
+                      (unsigned long long *)d_npairs, t_geo.d2max, 0u);
         // the home particles of over-full cells that the waves listed instead of processing (normally none:
         // the workgroups then return at once)
         PC_LAUNCH("pc_c3_heavy", pc_c3_heavy, dim3(resident >= 2048 ? 2048 : resident), dim3(PC_HV_TPB), (hipStream_t)stream,

@@ -25,12 +25,17 @@
 //
 // A cell whose home particles x candidates reach PC_G_HEAVY_COST is not processed
 // here: its home particles go on the list of pc_c3_heavy, as in variant 3.
-// Work is drawn from the segment list of pc_count_group.h (same counters).
+// Work is drawn from the segment list of pc_count_group.h (same counters) -- if most of the listed points lie in
+// well-filled segments; else the group kernel takes the list (pc_segments_go_to): below about 11 points per cell
+// the 64-candidate chunks are mostly empty lanes and that kernel is faster.
 #pragma once
 #include "pc_count_group.h"
 
 #ifndef PC_D_MAXCH
 #define PC_D_MAXCH 4                    // candidate chunks (of 64) held in registers at a time
+#endif
+#ifndef PC_DENSE_MIN_DEFAULT
+#define PC_DENSE_MIN_DEFAULT 11         // points per cell from which a segment counts as this kernel's kind
 #endif
 #ifndef PC_D_WAVES
 #define PC_D_WAVES 8                    // per SIMD (64 registers)
@@ -109,9 +114,11 @@ static_assert(PC_D_MAXCH >= 2 && PC_D_MAXCH <= 6, "pc_d_homes_n lists the chunk 
 __global__ void __launch_bounds__(64, PC_D_WAVES)
 pc_c6_count_dense(const float *__restrict__ pts_f, const uint32_t *__restrict__ T, int x_lo, int x_hi,
                   unsigned int *__restrict__ queue, uint32_t seg_cap, uint32_t heavy_cap,
-                  int gate, uint32_t gate_limit, unsigned long long *__restrict__ out, const float d2max)
+                  int gate, uint32_t gate_limit, unsigned long long *__restrict__ out, const float d2max,
+                  uint32_t dense_min)   // see pc_segments_go_to
 {
     if (!pc_gate_open(queue, gate, gate_limit)) return;
+    if (!pc_segments_go_to(queue, PC_SEGS_TO_DENSE, dense_min)) return;
     const pc_pt3 *__restrict__ pts = reinterpret_cast<const pc_pt3 *>(pts_f);
     const int lane = threadIdx.x;
     const int n_segments = (int)min(__builtin_amdgcn_readfirstlane(queue[PC_G_SEG_COUNT]), seg_cap);

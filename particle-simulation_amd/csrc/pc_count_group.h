@@ -76,6 +76,25 @@ __device__ __forceinline__ bool pc_gate_open(const unsigned int *queue, int gate
                            __builtin_amdgcn_readfirstlane(queue[PC_G_SEG_OVERFLOW]) != 0;
     return (gate == PC_GATE_IF_CLUSTERED) == clustered;
 }
+// Who works the segment list off on an even input is decided per call from what is on it: the points in segments of
+// well-filled cells (at least dense_min points per cell on average) and the points in the others are added up by
+// whoever lists a segment; pc_c6_count_dense takes the list if the former are the majority (its 64-candidate chunks
+// are full there), pc_c3_count_groups<false> if not (measured: the dense kernel loses below about 11 points per cell).
+#define PC_G_SEG_POINTS_DENSE 291
+#define PC_G_SEG_POINTS_THIN 292
+#define PC_SEGS_TO_DENSE 1               // which of the two kernels asks pc_segments_are_dense
+#define PC_SEGS_TO_GROUP 0
+__device__ __forceinline__ bool pc_segment_is_dense(uint32_t points, int cells, uint32_t dense_min)
+{
+    return (unsigned long long)points >= (unsigned long long)dense_min * (uint32_t)cells;
+}
+// (dense_min = 0: the caller has switched the choice off and launches only the kernel it wants)
+__device__ __forceinline__ bool pc_segments_go_to(const unsigned int *queue, int who, uint32_t dense_min)
+{
+    if (dense_min == 0) return true;
+    const bool dense = __builtin_amdgcn_readfirstlane(queue[PC_G_SEG_POINTS_DENSE]) >= __builtin_amdgcn_readfirstlane(queue[PC_G_SEG_POINTS_THIN]);
+    return dense == (who == PC_SEGS_TO_DENSE);
+}
 #define PC_G_HEAVY (PC_G_SEGS + 2 * PC_G_SEG_CAP)
 #define PC_G_HEAVY_CAP 65536
 #define PC_G_HEAVY_CHUNK 256
@@ -348,7 +367,8 @@ static_assert((unsigned long long)PC_G_PLAN_TARGET * PC_NLAYERS < 0xFFFFFFFFull,
 __global__ void __launch_bounds__(PC_G_PLAN_TPB)
 pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__restrict__ work, uint32_t seg_cap,
            uint32_t full_pencil,    // a pencil with more points than this counts as dense (several times the average)
-           const uint32_t *__restrict__ fgate)
+           const uint32_t *__restrict__ fgate,
+           uint32_t dense_min)      // points per cell from which a segment counts as well filled (0: not counted)
 {
     if (pc_fused_serves(fgate)) {
         if (blockIdx.x == 0 && threadIdx.x == 0) work[PC_G_SERVED] = 1;
@@ -357,6 +377,8 @@ pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__r
     __shared__ unsigned long long ends[PC_G_PLAN_PENCILS][PC_G_PLAN_STEPS];   // per 64 cells: the cells that close a segment
     __shared__ uint32_t seg_n[PC_G_PLAN_PENCILS], seg_at[PC_G_PLAN_PENCILS];
     __shared__ unsigned long long to_plan;
+    __shared__ uint32_t kind_points[2];        // points in the workgroup's thinly / well filled segments (see pc_segments_go_to)
+    if (threadIdx.x < 2) kind_points[threadIdx.x] = 0;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_pencils = (x_hi - x_lo) * PC_NLAYERS, per_wave = PC_G_PLAN_PENCILS / (PC_G_PLAN_TPB / 64);
     const uint32_t target = PC_G_PLAN_TARGET;
@@ -439,6 +461,11 @@ pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__r
                     const uint32_t w = at + (uint32_t)__popcll(below);
                     work[PC_G_SEGS + 2 * w] = pencil + 1;
                     work[PC_G_SEGS + 2 * w + 1] = (uint32_t)z_begin | ((uint32_t)(u * 64 + lane + 1) << 16);
+                    if (dense_min != 0) {                  // the segment's points, to the workgroup's sum of its kind
+                        const uint32_t *row = T + (uint64_t)pencil * PC_NBB;
+                        const uint32_t pts_seg = row[u * 64 + lane + 1] - row[z_begin];
+                        atomicAdd(&kind_points[pc_segment_is_dense(pts_seg, u * 64 + lane + 1 - z_begin, dense_min) ? 1 : 0], pts_seg);
+                    }
                 }
                 at += (uint32_t)__popcll(e);
                 if (e) z_after = u * 64 + 64 - __clzll(e);
@@ -448,6 +475,11 @@ pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__r
             for (uint32_t w = at + lane; w < seg_cap; w += 64) work[PC_G_SEGS + 2 * w] = 0;
         }
     }
+    if (dense_min != 0) {                                  // (one atomic per workgroup and kind: the sums are single addresses)
+        __syncthreads();
+        if (threadIdx.x < 2 && kind_points[threadIdx.x] != 0)
+            atomicAdd(work + (threadIdx.x ? PC_G_SEG_POINTS_DENSE : PC_G_SEG_POINTS_THIN), kind_points[threadIdx.x]);
+    }
 }
 
 // WHOLE_PENCILS false: the whole pencils have been counted by another kernel, only the listed segments are left
@@ -455,9 +487,11 @@ template <bool WHOLE_PENCILS>
 __global__ void __launch_bounds__(PC_G_WAVES * 64, 4)   // registers and LDS admit 5 waves per SIMD
 pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T, int x_lo, int x_hi,
                    unsigned int *__restrict__ queue, uint32_t seg_cap, uint32_t heavy_cap,
-                   int gate, uint32_t gate_limit, unsigned long long *__restrict__ out, const float d2max)
+                   int gate, uint32_t gate_limit, unsigned long long *__restrict__ out, const float d2max,
+                   uint32_t dense_min)   // segments only (WHOLE_PENCILS false): see pc_segments_go_to
 {
     if (!pc_gate_open(queue, gate, gate_limit)) return;
+    if (!WHOLE_PENCILS && !pc_segments_go_to(queue, PC_SEGS_TO_GROUP, dense_min)) return;
     __shared__ pc_group_lds lds_all[PC_G_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     pc_group_lds &L = lds_all[wave];

@@ -201,7 +201,8 @@ __device__ __forceinline__ uint32_t pc_m_steps(const pc_merge_lds &L, uint32_t n
 // list of pc_c3_count_groups if there is room, else counted here and now.
 __device__ __forceinline__ unsigned long long pc_m_defer(const float *__restrict__ pts, const uint32_t *__restrict__ T,
                                                          unsigned int *__restrict__ queue, uint32_t seg_cap,
-                                                         uint32_t pencil, int z0, uint32_t home_hi, int lane, const pc_geom &geo)
+                                                         uint32_t pencil, int z0, uint32_t home_hi, int lane, const pc_geom &geo,
+                                                         uint32_t dense_min)
 {
     uint32_t at = 0xFFFFFFFFu;
     if (lane == 0 && seg_cap != 0) {
@@ -209,6 +210,10 @@ __device__ __forceinline__ unsigned long long pc_m_defer(const float *__restrict
         if (at < seg_cap) {
             queue[PC_G_SEGS + 2 * at] = pencil + 1;
             queue[PC_G_SEGS + 2 * at + 1] = (uint32_t)z0 | ((uint32_t)PC_NLAYERS << 16);
+            if (dense_min != 0) {                          // the rest's points, to the sum of its kind (see pc_segments_go_to)
+                const uint32_t pts_seg = home_hi - T[(uint64_t)pencil * PC_NBB + z0];
+                atomicAdd(queue + (pc_segment_is_dense(pts_seg, PC_NLAYERS - z0, dense_min) ? PC_G_SEG_POINTS_DENSE : PC_G_SEG_POINTS_THIN), pts_seg);
+            }
         }
     }
     at = __builtin_amdgcn_readfirstlane(at);
@@ -225,7 +230,7 @@ __device__ __forceinline__ unsigned long long pc_m_defer(const float *__restrict
 __global__ void __launch_bounds__(64, PC_M_WAVES)
 pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T, int x_lo, int x_hi,
                    unsigned int *__restrict__ queue, uint32_t seg_cap, int gate, uint32_t gate_limit,
-                   unsigned long long *__restrict__ out, const pc_geom geo)
+                   unsigned long long *__restrict__ out, const pc_geom geo, uint32_t dense_min)
 {
     if (!pc_gate_open(queue, gate, gate_limit)) return;
     __shared__ pc_merge_lds L;
@@ -275,7 +280,7 @@ pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T
         // (the last table entry of layer i+1: its always-empty padding pencil starts where the layer's points end)
         const uint32_t reach = T[(uint32_t)(layer + 2) * PC_NBB2 - 1u] - home_lo;
         if (!skip && done != home_hi && reach > 0xFFFFFFFFu / 12u) {
-            acc += pc_m_defer(pts, T, queue, seg_cap, pencil, 0, home_hi, lane, geo);
+            acc += pc_m_defer(pts, T, queue, seg_cap, pencil, 0, home_hi, lane, geo, dense_min);
             done = home_hi;
         }
         // Lane t of a window starting at home cell z0 owns block S_{z0+t}: row 0 at cell z0+t, rows 1-4 at
@@ -320,7 +325,7 @@ pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T
             // run lengths: three blocks on average; beyond about 130 slots variant 3's kernel does better
             const bool suited = fits && 3u * tot <= PC_M_MAX_RUN * (uint32_t)nblk;
             if (!suited) {
-                const unsigned long long slow = pc_m_defer(pts, T, queue, seg_cap, pencil, z0, home_hi, lane, geo);
+                const unsigned long long slow = pc_m_defer(pts, T, queue, seg_cap, pencil, z0, home_hi, lane, geo, dense_min);
                 acc += slow;
                 break;
             }

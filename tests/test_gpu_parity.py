@@ -472,8 +472,9 @@ def test_density_regimes(psa, stages, torch_mod, oracle, shape):
 
 @pytest.mark.parametrize("shape", ["filled_slab", "pencil_100", "one_cell_700", "ragged", "face_pencils", "over_full"])
 def test_dense_segment_kernel(psa, stages, torch_mod, oracle, shape):
-    """The segments of cut pencils are worked off by the dense kernel (candidates in registers) or, with
-    pc_set_variant("dense", 0), by the group kernel: same count as the oracle either way.  The shapes cover one
+    """The segments of cut pencils are worked off by the dense kernel (candidates in registers) or by the group
+    kernel -- chosen on the device from how well the listed segments are filled, or forced with
+    pc_set_variant("dense", 2 / 0): same count as the oracle every way.  The shapes cover one
     chunk of home particles and one piece of candidates (the usual case), several of each (more than 64 points in
     a cell, more than 256 candidates), empty cells inside a segment, pencils at the faces of the grid (missing
     rows), and cells handed on to the over-full-cell kernel."""
@@ -503,11 +504,18 @@ def test_dense_segment_kernel(psa, stages, torch_mod, oracle, shape):
                               _cell_box(rng, 20_000, (120, 77, 0), (121, 78, 400))])
     xyz = xyz.astype(np.float32)
     want, want_tests = oracle.count_pairs(xyz)
-    for dense in (1, 0):
+    for dense in (1, 0, 2):                # chosen on the device from the listed segments / group kernel / dense kernel
         psa.set_variant("dense", dense)
         got, tests, _ = gpu_count(psa, stages, torch_mod, xyz, bin_v=1, count_v=5)
         assert got == want, (shape, dense)
         assert tests == want_tests
+    try:                                   # the device-side choice pushed both ways by its threshold
+        psa.set_variant("dense", 1)
+        for dense_min in (1, 65535):
+            psa.set_variant("dense_min", dense_min)
+            assert gpu_count(psa, stages, torch_mod, xyz, bin_v=1, count_v=5)[0] == want, (shape, dense_min)
+    finally:
+        psa.set_variant("dense_min", 11)
 
 
 def test_heavy_cell_list_overflow(psa, stages, torch_mod, oracle):
