@@ -312,7 +312,7 @@ static inline int grid_for(uint64_t n, int tpb, int cap);
 // load the code object and are not for a stream under capture, see pc_noalloc_prepare).
 struct launch_sizes {
     int ready;
-    int l7b_small, l7b_large;       // pc_l7b_sort_big_pencils, both instantiations
+    int l7b_small, l7b_medium, l7b_large;   // pc_l7b_sort_big_pencils, its instantiations
     int c3, c5, c6;                 // pc_c3_count_groups, pc_c5_count_merged, pc_c6_count_dense
 };
 static launch_sizes g_sizes[64];
@@ -415,9 +415,9 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
     if (n)
         PC_LAUNCH("pc_l6_partition_y", pc_l36_partition<1>, dim3(tiles + PC_NBB), dim3(PC_L_PTPB), s, d_sorted, n,
                   w.tmp, w.layer_start, w.layer_tile, w.tile_layer, w.pencil_cursor, w.ycell, t_geo);
-    // Level Z in three launches.  Pencils too big for a wave are listed by L5 (one workgroup each: two size classes,
+    // Level Z in four launches.  Pencils too big for a wave are listed by L5 (one workgroup each: three size classes,
     // fixed grids walk the list), those too big for a workgroup on a second list (tile-parallel histogram, scan,
-    // partition).  The three steps of the latter ride at the end of the three grids: see L7H in pc_bin_lds.h.
+    // partition).  The three steps of the latter ride at the end of three of the grids: see L7H in pc_bin_lds.h.
     const uint32_t first_pencil = (uint32_t)layer_lo * PC_NBB, end_pencil = (uint32_t)(layer_hi + 1) * PC_NBB;
     const uint32_t l7_blocks = (end_pencil - first_pencil + PC_L7_WAVES - 1) / PC_L7_WAVES;
     const dim3 l7_grid(l7_blocks + PC_L7H_GRID);
@@ -426,16 +426,21 @@ static int bin_lds(const float *d_xyz, uint64_t n, float *d_sorted, uint32_t *ta
                      : n > PC_L_STREAM_POINTS ? pc_l7_sort_pencils<PC_L7_CAP, true> : pc_l7_sort_pencils<PC_L7_CAP, false>;
     PC_LAUNCH("pc_l7_sort_pencils", l7, l7_grid, dim3(PC_L7_WAVES * 64), s, w.tmp, d_sorted, w.pencil_start, table, first_pencil,
               end_pencil, d_status, t_geo, fgate, l7_blocks, w.big_count + 1, w.huge_list, w.huge_count);
-    auto small = pc_l7b_sort_big_pencils<PC_L7B_CAP_SMALL, PC_L7B_TPB_SMALL>;
-    auto large = pc_l7b_sort_big_pencils<PC_L7B_CAP_LARGE, PC_L7B_TPB_LARGE>;
+    auto small = pc_l7b_sort_big_pencils<PC_L7B_CAP_SMALL, PC_L7B_TPB_SMALL, PC_L7B_ROLE_SCAN>;
+    auto medium = pc_l7b_sort_big_pencils<PC_L7B_CAP_MEDIUM, PC_L7B_TPB_MEDIUM, PC_L7B_ROLE_NONE>;
+    auto large = pc_l7b_sort_big_pencils<PC_L7B_CAP_LARGE, PC_L7B_TPB_LARGE, PC_L7B_ROLE_PARTITION>;
     const launch_sizes *sizes = nullptr;
     const int rc_sizes = launch_sizes_of_current_device(&sizes);
     if (rc_sizes) return rc_sizes;
     PC_LAUNCH("pc_l7b_sort_big_pencils", small, dim3(sizes->l7b_small + PC_L7H_SCAN_GRID), dim3(PC_L7B_TPB_SMALL), s, w.tmp, d_sorted,
               w.pencil_start, table, w.big_count, w.big_list, first_pencil, end_pencil, 0u, (uint32_t)PC_L7B_CAP_SMALL,
               (uint32_t)sizes->l7b_small, w.big_count + 1, w.huge_list, w.huge_count, w.huge_cursor, d_status, t_geo, fgate);
-    PC_LAUNCH("pc_l7b_sort_bigger_pencils", large, dim3(sizes->l7b_large + PC_L7H_GRID), dim3(PC_L7B_TPB_LARGE), s, w.tmp, d_sorted,
+    PC_LAUNCH("pc_l7b_sort_medium_pencils", medium, dim3(sizes->l7b_medium), dim3(PC_L7B_TPB_MEDIUM), s, w.tmp, d_sorted,
               w.pencil_start, table, w.big_count, w.big_list, first_pencil, end_pencil, (uint32_t)PC_L7B_CAP_SMALL,
+              (uint32_t)PC_L7B_CAP_MEDIUM, (uint32_t)sizes->l7b_medium, w.big_count + 1, w.huge_list, w.huge_count, w.huge_cursor,
+              d_status, t_geo, fgate);
+    PC_LAUNCH("pc_l7b_sort_bigger_pencils", large, dim3(sizes->l7b_large + PC_L7H_GRID), dim3(PC_L7B_TPB_LARGE), s, w.tmp, d_sorted,
+              w.pencil_start, table, w.big_count, w.big_list, first_pencil, end_pencil, (uint32_t)PC_L7B_CAP_MEDIUM,
               (uint32_t)PC_L7B_CAP_LARGE, (uint32_t)sizes->l7b_large, w.big_count + 1, w.huge_list, w.huge_count, w.huge_cursor,
               d_status, t_geo, fgate);
     PC_HIP(hipGetLastError());
@@ -616,8 +621,9 @@ static int launch_sizes_of_current_device(const launch_sizes **out)
             return pc_fail(PC_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
         }
         const int cus = prop.multiProcessorCount;
-        z->l7b_small = resident_blocks(pc_l7b_sort_big_pencils<PC_L7B_CAP_SMALL, PC_L7B_TPB_SMALL>, PC_L7B_TPB_SMALL, cus, 4);
-        z->l7b_large = resident_blocks(pc_l7b_sort_big_pencils<PC_L7B_CAP_LARGE, PC_L7B_TPB_LARGE>, PC_L7B_TPB_LARGE, cus, 1);
+        z->l7b_small = resident_blocks(pc_l7b_sort_big_pencils<PC_L7B_CAP_SMALL, PC_L7B_TPB_SMALL, PC_L7B_ROLE_SCAN>, PC_L7B_TPB_SMALL, cus, 4);
+        z->l7b_medium = resident_blocks(pc_l7b_sort_big_pencils<PC_L7B_CAP_MEDIUM, PC_L7B_TPB_MEDIUM, PC_L7B_ROLE_NONE>, PC_L7B_TPB_MEDIUM, cus, 2);
+        z->l7b_large = resident_blocks(pc_l7b_sort_big_pencils<PC_L7B_CAP_LARGE, PC_L7B_TPB_LARGE, PC_L7B_ROLE_PARTITION>, PC_L7B_TPB_LARGE, cus, 1);
         z->c3 = resident_blocks(pc_c3_count_groups<true>, PC_G_WAVES * 64, cus, 16);
         z->c5 = resident_blocks(pc_c5_count_merged, 64, cus, 16);
         z->c6 = resident_blocks(pc_c6_count_dense, 64, cus, 16);

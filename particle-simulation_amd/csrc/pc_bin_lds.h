@@ -792,17 +792,22 @@ pc_l7_sort_pencils(const float *__restrict__ src, float *__restrict__ dst,
 // ---- L7B: one workgroup sorts one big pencil ------------------------------------
 // Pencils with more points than a wave of L7 keeps (clustered inputs, or more than
 // about 2 points per cell everywhere) are listed by L5.  Its points go through
-// registers and an LDS copy in cell order like L7's.  Two instantiations share the
+// registers and an LDS copy in cell order like L7's.  Three instantiations share the
 // list: a small one (several workgroups per CU) takes the pencils of at most
-// PC_L7B_CAP_SMALL points, a large one those of up to PC_L7B_CAP_LARGE; what is
+// PC_L7B_CAP_SMALL points, a medium and a large one those of up to PC_L7B_CAP_MEDIUM and PC_L7B_CAP_LARGE; what is
 // larger still is on L5's second list and sorted tile by tile (L7H above).  The
 // first sort_blocks workgroups of the grid sort; the rest take a step of L7H.
 #define PC_L7B_CAP_SMALL 2048
 #define PC_L7B_TPB_SMALL 256
+#define PC_L7B_CAP_MEDIUM 4096                     // (48 KB of LDS: three workgroups per CU where the large one gets one)
+#define PC_L7B_TPB_MEDIUM 512
 #define PC_L7B_CAP_LARGE 8192
 #define PC_L7B_TPB_LARGE 512
+#define PC_L7B_ROLE_NONE 0                         // what the workgroups behind the sorting ones do (a step of L7H)
+#define PC_L7B_ROLE_SCAN 1
+#define PC_L7B_ROLE_PARTITION 2
 
-template <int PC_L7B_CAP, int PC_L7B_TPB>
+template <int PC_L7B_CAP, int PC_L7B_TPB, int PC_L7B_ROLE>
 __global__ void __launch_bounds__(PC_L7B_TPB)
 pc_l7b_sort_big_pencils(const float *__restrict__ src, float *__restrict__ dst,
                         const uint32_t *__restrict__ pencil_start, uint32_t *__restrict__ table,
@@ -818,11 +823,11 @@ pc_l7b_sort_big_pencils(const float *__restrict__ src, float *__restrict__ dst,
     __shared__ float stage[PC_L7B_CAP * 3];
     if (blockIdx.x >= sort_blocks) {                   // the workgroups behind the sorting ones: a step of L7H (normally nothing to do)
         const uint32_t blk = blockIdx.x - sort_blocks, nblk = gridDim.x - sort_blocks;
-        if constexpr (PC_L7B_CAP == PC_L7B_CAP_SMALL)
+        if constexpr (PC_L7B_ROLE == PC_L7B_ROLE_SCAN)
             pc_l7h_scan_role(blk, nblk, hist, pencil_start, huge_n, huge_list, huge_count, huge_cursor, table);
-        else {
-            static_assert(PC_L7B_CAP == PC_L7B_CAP_SMALL || PC_L7B_TPB == PC_L_PTPB, "the partition role runs with PC_L_PTPB threads");
-            static_assert(PC_L7B_CAP == PC_L7B_CAP_SMALL ||
+        else if constexpr (PC_L7B_ROLE == PC_L7B_ROLE_PARTITION) {
+            static_assert(PC_L7B_ROLE != PC_L7B_ROLE_PARTITION || PC_L7B_TPB == PC_L_PTPB, "the partition role runs with PC_L_PTPB threads");
+            static_assert(PC_L7B_ROLE != PC_L7B_ROLE_PARTITION ||
                           PC_L7B_CAP * 3 >= PC_L7H_TILE * 3 + PC_L7H_TILE / 2 + 2 * PC_L_BINS, "the partition role's arrays lie inside `stage`");
             uint32_t *words = reinterpret_cast<uint32_t *>(stage + PC_L7H_TILE * 3 + PC_L7H_TILE / 2);
             pc_l7h_partition_role(blk, nblk, stage, reinterpret_cast<uint16_t *>(stage + PC_L7H_TILE * 3), hist, words, words + PC_L_BINS,
