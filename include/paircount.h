@@ -278,7 +278,9 @@ int pc_count_pairs_noalloc(const float *d_xyz, uint64_t n, int x_lo, int x_hi,
    per call on the device -- the candidates-in-registers kernel if most of the
    listed points lie in segments with at least "dense_min" (default 11) points per
    cell, else the group kernel; 0: the group kernel; 2: the candidates-in-registers
-   kernel), or "even": whether the
+   kernel), or "clustered_share": the percentage of the points that must sit in
+   pencils of more than four average pencils for an input to count as clustered
+   (default 12; the group kernel then takes the whole pair test), or "even": whether the
    merged-window pair test's grid is cut down to a whole number of pencils per wave
    (1, the default; 0: as many waves as are resident).  Returns PC_ERR_ARG for an
    unknown name or value. */
