@@ -1564,3 +1564,20 @@ extern "C" int pc_trace_read(unsigned long long out[16])
     return PC_OK;
 }
 #endif
+
+#ifdef PC_G_TRACE
+// Measurement build only: reads and clears the group kernel's per-part cycle and window counters (see pc_count_group.h).
+extern "C" int pc_group_trace_read(unsigned long long out[16])
+{
+    static unsigned long long rows[64][16];
+    PC_HIP(hipDeviceSynchronize());
+    PC_HIP(hipMemcpyFromSymbol(rows, HIP_SYMBOL(pc_g_trace), sizeof rows));
+    for (int i = 0; i < 16; i++) {
+        out[i] = 0;
+        for (int r = 0; r < 64; r++) out[i] += rows[r][i];
+    }
+    memset(rows, 0, sizeof rows);
+    PC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pc_g_trace), rows, sizeof rows));
+    return PC_OK;
+}
+#endif

@@ -482,6 +482,23 @@ pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__r
     }
 }
 
+#ifdef PC_G_TRACE
+// Measurement build only: shader-clock cycles a wave of the group kernel spends in each part of its work, kept in
+// scalar registers and added at the wave's end to one of 64 rows; [row][0..7] cycles, [row][8..15] windows.
+// 0 table reads and window bookkeeping, 1 copy into LDS, 2 steps of 2-lane groups, 3 of 4-lane groups, 4 of 8-lane
+// groups, 5 register blocks of a dense window, 6 its same-pencil pairs, 7 a cell that does not fit the buffers.
+__device__ unsigned long long pc_g_trace[64][16];
+#define PC_G_MARK(i)                                                      \
+    do {                                                                   \
+        const unsigned long long now_ = __builtin_readcyclecounter();     \
+        tr_[i] += now_ - mark_;                                            \
+        tr_[8 + (i)] += 1;                                                 \
+        mark_ = now_;                                                      \
+    } while (0)
+#else
+#define PC_G_MARK(i) do { } while (0)
+#endif
+
 // WHOLE_PENCILS false: the whole pencils have been counted by another kernel, only the listed segments are left
 template <bool WHOLE_PENCILS>
 __global__ void __launch_bounds__(PC_G_WAVES * 64, 4)   // registers and LDS admit 5 waves per SIMD
@@ -496,6 +513,9 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     pc_group_lds &L = lds_all[wave];
     unsigned long long acc = 0;          // per-lane partial (lane 0 also carries the wave-uniform hit counts)
+#ifdef PC_G_TRACE
+    unsigned long long tr_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, mark_ = __builtin_readcyclecounter();
+#endif
 
     // Persistent waves with a work queue per XCD group.  Workgroups with equal
     // blockIdx%8 share an XCD; that group owns the band of 50 pencils
@@ -614,6 +634,7 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                 }
             }
 
+            PC_G_MARK(0);
             if (fits) {
                 const uint32_t tot_m = pc_lane_value(cum_m, t_last);
                 const uint32_t tot_h = pc_lane_value(cum_h, t_last);       // row-0 points staged (home cells + cell above)
@@ -684,17 +705,18 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                     pc_dma_wait();
                     if (lane <= t_last && (nm_pts & 1)) L.x[ex_m + nm_pts] = __builtin_nanf("");   // ... and then never matches
                     pc_wave_lds_sync();
+                    PC_G_MARK(1);
                     // ---- rows 1-4: candidate-parallel steps, group size from the mean range length
                     // candidates per pass (2*G*NP) should cover mean + 2 sigma of a Poisson range length:
                     // m + 2*sqrt(m) + 1 <= 8, 16, 32, 64, 128  <=>  m <= 3, 9, 22, 49, 106
                     // (mean = 3 * tot_m / cells, compared without dividing)
                     const uint32_t m3 = 3u * tot_m, cells = (uint32_t)(t_last + 1);
                     uint32_t hits;
-                    if (m3 < 4 * cells) hits = pc_g_window<2, 2>(L, nh, lane, d2max);
-                    else if (m3 < 10 * cells) hits = pc_g_window<2, 4>(L, nh, lane, d2max);
-                    else if (m3 < 23 * cells) hits = pc_g_window<2, 8>(L, nh, lane, d2max);
-                    else if (m3 < 50 * cells) hits = pc_g_window<4, 8>(L, nh, lane, d2max);
-                    else if (m3 < 107 * cells) hits = pc_g_window<8, 8>(L, nh, lane, d2max);
+                    if (m3 < 4 * cells) { hits = pc_g_window<2, 2>(L, nh, lane, d2max); PC_G_MARK(2); }
+                    else if (m3 < 10 * cells) { hits = pc_g_window<2, 4>(L, nh, lane, d2max); PC_G_MARK(2); }
+                    else if (m3 < 23 * cells) { hits = pc_g_window<2, 8>(L, nh, lane, d2max); PC_G_MARK(2); }
+                    else if (m3 < 50 * cells) { hits = pc_g_window<4, 8>(L, nh, lane, d2max); PC_G_MARK(3); }
+                    else if (m3 < 107 * cells) { hits = pc_g_window<8, 8>(L, nh, lane, d2max); PC_G_MARK(4); }
                     else {
                         // dense window: per home cell, candidates stay in registers while the
                         // cell's home particles stream by
@@ -704,6 +726,7 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                             const uint32_t hb = pc_lane_value(ex_h, t), he = hb + pc_lane_value(n[0], t);
                             hits += pc_g_block<false>(L, c_lo, c_hi, hb, he, lane, d2max);
                         }
+                        PC_G_MARK(5);
                         // same pencil (the steps above count these themselves): lane per home particle
                         for (uint32_t hp = lane; hp < nh; hp += 64) {
                             const float mx = L.hx[hp], my = L.hy[hp], mz = L.hz[hp];
@@ -718,6 +741,7 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                             }
                             acc += cnt;
                         }
+                        PC_G_MARK(6);
                     }
                     if (lane == 0) acc += hits;
                     pc_wave_lds_sync();
@@ -792,11 +816,16 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                     }
                 }
                 done = h0 + pc_lane_value(n[0], th0);
+                PC_G_MARK(7);
             }
             z0 = z_next;
         }
         m = __builtin_amdgcn_readfirstlane(m_next);
     }
+#ifdef PC_G_TRACE
+    if (lane == 0)
+        for (int i = 0; i < 16; i++) atomicAdd(&pc_g_trace[blockIdx.x % 64][i], tr_[i]);
+#endif
     pc_block_add_u64<PC_G_WAVES>(acc, out);
 }
 
