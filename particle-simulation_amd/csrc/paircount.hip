@@ -1567,12 +1567,12 @@ extern "C" int pc_trace_read(unsigned long long out[16])
 
 #ifdef PC_G_TRACE
 // Measurement build only: reads and clears the group kernel's per-part cycle and window counters (see pc_count_group.h).
-extern "C" int pc_group_trace_read(unsigned long long out[16])
+extern "C" int pc_group_trace_read(unsigned long long out[32])
 {
-    static unsigned long long rows[64][16];
+    static unsigned long long rows[64][32];
     PC_HIP(hipDeviceSynchronize());
     PC_HIP(hipMemcpyFromSymbol(rows, HIP_SYMBOL(pc_g_trace), sizeof rows));
-    for (int i = 0; i < 16; i++) {
+    for (int i = 0; i < 32; i++) {
         out[i] = 0;
         for (int r = 0; r < 64; r++) out[i] += rows[r][i];
     }

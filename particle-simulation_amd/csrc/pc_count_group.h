@@ -482,17 +482,72 @@ pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__r
     }
 }
 
+// One home cell against its whole neighbourhood, the candidates going through the merged arrays in pieces: home
+// particles [h0, h1) of the sorted array, candidate ranges [c_lo[r], c_hi[r]) -- row 0 from h0 to the end of the cell
+// above, rows 1-4 three cells each.  The five ranges are taken as ONE list, row 0 first (its "later slots only"
+// rule, main.c:215-221, then reads "list index at least i + 1 - h0" for home particle i, and everything behind
+// row 0 pairs with every home particle), cut into pieces of 384 = 256 + 128 candidates (full register blocks)
+// until what is left fits the buffer: the part-filled block comes once per cell, not once per row.
+__device__ __forceinline__ uint32_t pc_g_cell(pc_group_lds &L, const float *__restrict__ pts, uint32_t h0, uint32_t h1,
+                                              const uint32_t c_lo[5], const uint32_t c_hi[5], int lane, float d2max)
+{
+    uint32_t hits = 0;
+    uint32_t v_end[5];                     // list index behind each range
+    v_end[0] = c_hi[0] - c_lo[0];
+#pragma unroll
+    for (int r = 1; r < 5; r++) v_end[r] = v_end[r - 1] + (c_hi[r] - c_lo[r]);
+    const uint32_t ctot = v_end[4];
+    for (uint32_t v0 = 0; v0 < ctot;) {
+        const uint32_t cnt = ctot - v0 <= (uint32_t)PC_G_CAPM ? ctot - v0 : 384u;
+#pragma unroll
+        for (int qq = 0; qq < PC_G_CAPM / 64; qq++) {
+            if (64u * qq < cnt) {
+                const uint32_t v = v0 + min(lane + 64u * qq, cnt - 1);
+                uint32_t slot = c_lo[0] + v;
+#pragma unroll
+                for (int r = 1; r < 5; r++)
+                    if (v >= v_end[r - 1]) slot = c_lo[r] + (v - v_end[r - 1]);
+                pc_dma_point(pts + 3 * (uint64_t)slot, L.x + 64 * qq, L.y + 64 * qq, L.z + 64 * qq);
+            }
+        }
+        const bool own = v0 < h1 - h0;     // the piece holds slots of the home cell itself
+        // the cell's home particles in batches: every lane works on the
+        // piece's candidates for one home particle at a time (G = 64)
+        for (uint32_t hb = h0; hb < h1; hb += PC_G_CAPH) {
+            const uint32_t nhb = min((uint32_t)PC_G_CAPH, h1 - hb);
+#pragma unroll
+            for (int qq = 0; qq < PC_G_CAPH / 64; qq++) {
+                const uint32_t e = lane + 64 * qq;
+                if (64u * qq < nhb)
+                    pc_dma_point(pts + 3 * (uint64_t)(e < nhb ? hb + e : hb), L.hx + 64 * qq, L.hy + 64 * qq, L.hz + 64 * qq);
+                if (e < nhb) {
+                    const uint32_t first = hb + e + 1 - h0;              // list index of the slot after the home particle
+                    const uint32_t lo = first > v0 ? min(first - v0, cnt) : 0u;
+                    L.meta[e] = make_uint2(lo | (cnt << 16), 0u);
+                }
+            }
+            pc_dma_wait();
+            pc_wave_lds_sync();
+            hits += own ? pc_g_block<true>(L, 0, cnt, 0, nhb, lane, d2max) : pc_g_block<false>(L, 0, cnt, 0, nhb, lane, d2max);
+            pc_wave_lds_sync();
+        }
+        v0 += cnt;
+    }
+    return hits;
+}
+
 #ifdef PC_G_TRACE
 // Measurement build only: shader-clock cycles a wave of the group kernel spends in each part of its work, kept in
-// scalar registers and added at the wave's end to one of 64 rows; [row][0..7] cycles, [row][8..15] windows.
+// scalar registers and added at the wave's end to one of 64 rows; [row][0..15] cycles, [row][16..31] times.
 // 0 table reads and window bookkeeping, 1 copy into LDS, 2 steps of 2-lane groups, 3 of 4-lane groups, 4 of 8-lane
-// groups, 5 register blocks of a dense window, 6 its same-pencil pairs, 7 a cell that does not fit the buffers.
-__device__ unsigned long long pc_g_trace[64][16];
+// groups, 5 register blocks of a dense window, 6 its same-pencil pairs; a cell that does not fit the buffers: 7 its set-up,
+// 8 the cell itself (pc_g_cell).
+__device__ unsigned long long pc_g_trace[64][32];
 #define PC_G_MARK(i)                                                      \
     do {                                                                   \
         const unsigned long long now_ = __builtin_readcyclecounter();     \
         tr_[i] += now_ - mark_;                                            \
-        tr_[8 + (i)] += 1;                                                 \
+        tr_[16 + (i)] += 1;                                                \
         mark_ = now_;                                                      \
     } while (0)
 #else
@@ -514,7 +569,7 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
     pc_group_lds &L = lds_all[wave];
     unsigned long long acc = 0;          // per-lane partial (lane 0 also carries the wave-uniform hit counts)
 #ifdef PC_G_TRACE
-    unsigned long long tr_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, mark_ = __builtin_readcyclecounter();
+    unsigned long long tr_[32] = {}, mark_ = __builtin_readcyclecounter();
 #endif
 
     // Persistent waves with a work queue per XCD group.  Workgroups with equal
@@ -779,44 +834,13 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                         if (room) h1 = h0;                  // nothing left to do for this cell here
                     }
                 }
-#pragma unroll
-                for (int r = 0; r < 5; r++) {
-                    if (h0 == h1) break;                   // no home particle in this cell
-                    for (uint32_t p0 = c_lo[r]; p0 < c_hi[r]; p0 += PC_G_CAPM) {
-                        const uint32_t cnt = min((uint32_t)PC_G_CAPM, c_hi[r] - p0);
-#pragma unroll
-                        for (int qq = 0; qq < PC_G_CAPM / 64; qq++) {
-                            const uint32_t e = lane + 64 * qq;
-                            if (64u * qq < cnt)
-                                pc_dma_point(pts + 3 * (uint64_t)(e < cnt ? p0 + e : p0), L.x + 64 * qq, L.y + 64 * qq, L.z + 64 * qq);
-                        }
-                        // the cell's home particles in batches: every lane works on the
-                        // piece's candidates for one home particle at a time (G = 64)
-                        for (uint32_t hb = h0; hb < h1; hb += PC_G_CAPH) {
-                            const uint32_t nhb = min((uint32_t)PC_G_CAPH, h1 - hb);
-#pragma unroll
-                            for (int qq = 0; qq < PC_G_CAPH / 64; qq++) {
-                                const uint32_t e = lane + 64 * qq;
-                                if (64u * qq < nhb)
-                                    pc_dma_point(pts + 3 * (uint64_t)(e < nhb ? hb + e : hb), L.hx + 64 * qq, L.hy + 64 * qq, L.hz + 64 * qq);
-                                if (e < nhb) {
-                                    const uint32_t i = hb + e;
-                                    uint32_t lo = 0;
-                                    if (r == 0 && i + 1 > p0) lo = min(i + 1 - p0, cnt);   // row 0: only slots after i
-                                    L.meta[e] = make_uint2(lo | (cnt << 16), 0u);
-                                }
-                            }
-                            pc_dma_wait();
-                            pc_wave_lds_sync();
-                            const uint32_t hits = r == 0 ? pc_g_block<true>(L, 0, cnt, 0, nhb, lane, d2max)
-                                                         : pc_g_block<false>(L, 0, cnt, 0, nhb, lane, d2max);
-                            if (lane == 0) acc += hits;
-                            pc_wave_lds_sync();
-                        }
-                    }
+                PC_G_MARK(7);
+                if (h0 != h1) {
+                    const uint32_t hits = pc_g_cell(L, pts, h0, h1, c_lo, c_hi, lane, d2max);
+                    if (lane == 0) acc += hits;
+                    PC_G_MARK(8);
                 }
                 done = h0 + pc_lane_value(n[0], th0);
-                PC_G_MARK(7);
             }
             z0 = z_next;
         }
@@ -824,7 +848,7 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
     }
 #ifdef PC_G_TRACE
     if (lane == 0)
-        for (int i = 0; i < 16; i++) atomicAdd(&pc_g_trace[blockIdx.x % 64][i], tr_[i]);
+        for (int i = 0; i < 32; i++) atomicAdd(&pc_g_trace[blockIdx.x % 64][i], tr_[i]);
 #endif
     pc_block_add_u64<PC_G_WAVES>(acc, out);
 }

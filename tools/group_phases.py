@@ -16,8 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 PARTS = ["table reads + window bookkeeping", "copy into LDS (list, DMA, ranges)", "steps, 2-lane groups", "steps, 4-lane groups",
-         "steps, 8-lane groups", "dense window: register blocks", "dense window: same-pencil pairs", "cell that does not fit"]
-
+         "steps, 8-lane groups", "dense window: register blocks", "dense window: same-pencil pairs", "cell that does not fit: set-up",
+         "  the cell, piece by piece (pc_g_cell)"]
 
 def main():
     ap = argparse.ArgumentParser()
@@ -52,7 +52,7 @@ def main():
         psa.set_variant("count", args.count_variant)
     st = psa.DeviceStages(xyz.shape[0], "cuda:0")
     st.count_pairs(xyz, x_lo, x_hi)
-    out = (ctypes.c_ulonglong * 16)()
+    out = (ctypes.c_ulonglong * 32)()
     raw = ctypes.CDLL(os.path.abspath(args.lib))
     assert raw.pc_group_trace_read(out) == 0          # (clears the counters of the warm-up)
     reps = 3
@@ -67,10 +67,10 @@ def main():
             print("%s: %.3f ms per launch in this build" % (k, ms / timed))
     print("pairs %d" % st.pairs())
     v = [int(x) for x in out]
-    total = sum(v[:8])
+    total = sum(v[:16])
     for i, name in enumerate(PARTS):
         print("   %-40s %5.1f %% of the waves' cycles  %10d times per run  %8.0f cycles each"
-              % (name, 100.0 * v[i] / max(total, 1), v[8 + i] // reps, v[i] / max(v[8 + i], 1)))
+              % (name, 100.0 * v[i] / max(total, 1), v[16 + i] // reps, v[i] / max(v[16 + i], 1)))
 
 
 if __name__ == "__main__":
