@@ -29,28 +29,52 @@ __device__ __forceinline__ uint32_t pc_count_one_home(const float *__restrict__ 
     const uint32_t c = pc_key(ci, cj, ck);
     uint32_t cnt = 0;
     // the five candidate ranges: same cell (later slots) with cell c+1 = slots (p, T[c+2]), then the
-    // three-cell runs of the four neighbour pencils; all ten table reads are issued before any is used
+    // three-cell runs of the four neighbour pencils.  A run's first and last table entry lie 12 bytes apart:
+    // one 16-byte load per run, and all five table reads are issued before any is used.
     const uint32_t base[5] = {0u, 402u, 162005u, 162408u, 162811u};
-    uint32_t lo[5], hi[5];
-    lo[0] = p + 1;
-    hi[0] = T[c + 2];
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const uint32_t own_hi = T[c + 2];
+    u4 run[5];
+    // (written as one block: the compiler would load the first and the last entry with two 4-byte loads, and it
+    // must not touch the destination registers before the loads have returned)
+    asm volatile("global_load_dwordx4 %0, %4, off\n\t"
+                 "global_load_dwordx4 %1, %5, off\n\t"
+                 "global_load_dwordx4 %2, %6, off\n\t"
+                 "global_load_dwordx4 %3, %7, off\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(run[1]), "=&v"(run[2]), "=&v"(run[3]), "=&v"(run[4])
+                 : "v"(T + (c + base[1])), "v"(T + (c + base[2])), "v"(T + (c + base[3])), "v"(T + (c + base[4]))
+                 : "memory");
+    // The five ranges as ONE list (one loop whose length is the lane's total, not five loops that each run as long
+    // as the wave's longest): list index t is sorted slot t + shift[r] for the range r it falls into.
+    uint32_t first[6], shift[5];
+    first[0] = 0;
+    shift[0] = p + 1;
+    // (after a domain error the binning leaves slots unwritten, and such a slot may hold an older call's point of
+    // some other cell: its row-0 range is then empty or meaningless, never negative)
+    first[1] = own_hi > p + 1 ? own_hi - (p + 1) : 0u;
 #pragma unroll
     for (int r = 1; r < 5; r++) {
-        lo[r] = T[c + base[r]];
-        hi[r] = T[c + base[r] + 3];
+        shift[r] = run[r].x - first[r];
+        first[r + 1] = first[r] + (run[r].w - run[r].x);
     }
+    const uint32_t total = first[5];
     // two candidates per turn, packed arithmetic (v_pk_add/mul_f32); the second one of an odd tail is masked
     typedef float v2f __attribute__((ext_vector_type(2)));
     const v2f ax = {x, x}, ay = {y, y}, az = {z, z};
+    for (uint32_t t = 0; t < total; t += 2) {
+        const uint32_t t1 = min(t + 1, total - 1);
+        uint32_t s0 = shift[0], s1 = shift[0];
 #pragma unroll
-    for (int r = 0; r < 5; r++) {
-        for (uint32_t q = lo[r]; q < hi[r]; q += 2) {
-            const pt3 v0 = P[q], v1 = P[min(q + 1, hi[r] - 1)];
-            const v2f cx = {v0.x, v1.x}, cy = {v0.y, v1.y}, cz = {v0.z, v1.z};
-            const v2f dx = ax - cx, dy = ay - cy, dz = az - cz;
-            const v2f sq = (dx * dx + dy * dy) + dz * dz;            // unfused: see the build flags
-            cnt += (sq.x <= geo.d2max) + ((sq.y <= geo.d2max) & (q + 1 < hi[r]));
+        for (int r = 1; r < 5; r++) {
+            s0 = t >= first[r] ? shift[r] : s0;
+            s1 = t1 >= first[r] ? shift[r] : s1;
         }
+        const pt3 v0 = P[t + s0], v1 = P[t1 + s1];
+        const v2f cx = {v0.x, v1.x}, cy = {v0.y, v1.y}, cz = {v0.z, v1.z};
+        const v2f dx = ax - cx, dy = ay - cy, dz = az - cz;
+        const v2f sq = (dx * dx + dy * dy) + dz * dz;            // unfused: see the build flags
+        cnt += (sq.x <= geo.d2max) + ((sq.y <= geo.d2max) & (t + 1 < total));
     }
     return cnt;
 }
