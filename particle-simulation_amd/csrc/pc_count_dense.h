@@ -25,7 +25,7 @@
 //
 // A cell whose home particles x candidates reach PC_G_HEAVY_COST is not processed
 // here: its home particles go on the list of pc_c3_heavy, as in variant 3.
-// Work is drawn from the segment list of pc_count_group.h (same counters) -- if most of the listed points lie in
+// Work is drawn from the segment list of pc_count_group.h (its own draw counters, one per XCD group) -- if most of the listed points lie in
 // well-filled segments; else the group kernel takes the list (pc_segments_go_to): below about 11 points per cell
 // the 64-candidate chunks are mostly empty lanes and that kernel is faster.
 #pragma once
@@ -124,12 +124,24 @@ pc_c6_count_dense(const float *__restrict__ pts_f, const uint32_t *__restrict__ 
     const int n_segments = (int)min(__builtin_amdgcn_readfirstlane(queue[PC_G_SEG_COUNT]), seg_cap);
     if (n_segments == 0) return;                               // (nothing was added to the sum: no atomic either)
     unsigned long long acc = 0;                                // lane 0 carries the wave-uniform hit counts
-    int m = 0;
-    if (lane == 0) m = (int)atomicAdd(queue + PC_G_SEG_DRAW, 1u);
-    m = __builtin_amdgcn_readfirstlane(m);
-    while (m < n_segments) {
+    // The list is cut into eight contiguous parts, one per XCD group (workgroups with equal blockIdx % 8 share an XCD
+    // and its L2): neighbouring segments -- neighbouring pencils, whose points are each other's candidates -- are
+    // then worked on under one L2.  Each part has its own draw counter (the word behind the group's band counter,
+    // zeroed with it); a wave whose part is used up moves on to the next group's.
+    const int per_group = (n_segments + 7) >> 3;
+    int g = blockIdx.x & 7, groups_done = 0, m_local = 0;
+    if (lane == 0) m_local = (int)atomicAdd(queue + g * PC_G_QUEUE_STRIDE + 1, 1u);
+    m_local = __builtin_amdgcn_readfirstlane(m_local);
+    for (;;) {
+        while (m_local >= min(per_group, n_segments - g * per_group) && ++groups_done < 8) {
+            g = (g + 1) & 7;
+            if (lane == 0) m_local = (int)atomicAdd(queue + g * PC_G_QUEUE_STRIDE + 1, 1u);
+            m_local = __builtin_amdgcn_readfirstlane(m_local);
+        }
+        if (m_local >= min(per_group, n_segments - g * per_group)) break;
+        const int m = g * per_group + m_local;
         int m_next = 0;
-        if (lane == 0) m_next = (int)atomicAdd(queue + PC_G_SEG_DRAW, 1u);   // (its latency hides behind the segment)
+        if (lane == 0) m_next = (int)atomicAdd(queue + g * PC_G_QUEUE_STRIDE + 1, 1u);   // (its latency hides behind the segment)
         const uint32_t who = __builtin_amdgcn_readfirstlane(queue[PC_G_SEGS + 2 * m]);
         const uint32_t span = __builtin_amdgcn_readfirstlane(queue[PC_G_SEGS + 2 * m + 1]);
         if (who != 0) {                                        // (0: slot left empty by a pencil that did not fit the list)
@@ -214,7 +226,7 @@ pc_c6_count_dense(const float *__restrict__ pts_f, const uint32_t *__restrict__ 
                 if (lane == 0) acc += hits;
             }
         }
-        m = __builtin_amdgcn_readfirstlane(m_next);
+        m_local = __builtin_amdgcn_readfirstlane(m_next);
     }
     pc_block_add_u64<1>(acc, out);
 }

@@ -37,7 +37,7 @@
 // Heavy pencils (clustered inputs) are cut into z segments of roughly equal cost
 // by a planning kernel and handed out one segment at a time after the whole
 // pencils.  Layout of the work area (32-bit words):
-//   [0, 256)                      the eight band counters
+//   [0, 256)                      the eight band counters (word 32 g), each followed by the dense kernel's draw counter of group g
 //   [PC_G_SEG_COUNT]              segments planned        [PC_G_SEG_DRAW] segments handed out
 //   [PC_G_FLAGS, +PC_G_FLAG_WORDS)   one byte per pencil: 1 = planned as segments
 //   [PC_G_SEGS, +2*PC_G_SEG_CAP)     segments: pencil + 1 (0 = empty slot), z_begin | z_end << 16
