@@ -305,14 +305,12 @@ __device__ __forceinline__ uint32_t pc_g_chunk(const pc_group_lds &L, uint32_t p
     uint32_t hits = 0;
     const uint32_t p = p0 + lane;
     pc_v2f x[PAIRS], y[PAIRS], z[PAIRS];
-    unsigned long long ok[2 * PAIRS];
+    const float never = __builtin_nanf("");                  // a slot behind the range never matches: no mask per home particle
 #pragma unroll
     for (int c = 0; c < PAIRS; c++) {
-        x[c] = pc_v2f{L.x[p + 128 * c], L.x[p + 128 * c + 64]};
+        x[c] = pc_v2f{p + 128 * c < c_hi ? L.x[p + 128 * c] : never, p + 128 * c + 64 < c_hi ? L.x[p + 128 * c + 64] : never};
         y[c] = pc_v2f{L.y[p + 128 * c], L.y[p + 128 * c + 64]};
         z[c] = pc_v2f{L.z[p + 128 * c], L.z[p + 128 * c + 64]};
-        ok[2 * c] = __builtin_amdgcn_ballot_w64(p + 128 * c < c_hi);
-        ok[2 * c + 1] = __builtin_amdgcn_ballot_w64(p + 128 * c + 64 < c_hi);
     }
     for (uint32_t hp = h_lo; hp < h_hi; hp++) {
         const float hx = L.hx[hp], hy = L.hy[hp], hz = L.hz[hp];
@@ -323,8 +321,8 @@ __device__ __forceinline__ uint32_t pc_g_chunk(const pc_group_lds &L, uint32_t p
         for (int c = 0; c < PAIRS; c++) {
             const pc_v2f dx = ax - x[c], dy = ay - y[c], dz = az - z[c];
             const pc_v2f sq = (dx * dx + dy * dy) + dz * dz;
-            unsigned long long b0 = __builtin_amdgcn_ballot_w64(sq.x <= d2max) & ok[2 * c];
-            unsigned long long b1 = __builtin_amdgcn_ballot_w64(sq.y <= d2max) & ok[2 * c + 1];
+            unsigned long long b0 = __builtin_amdgcn_ballot_w64(sq.x <= d2max);
+            unsigned long long b1 = __builtin_amdgcn_ballot_w64(sq.y <= d2max);
             if (USE_LO) {
                 b0 &= __builtin_amdgcn_ballot_w64(p + 128 * c >= lo);
                 b1 &= __builtin_amdgcn_ballot_w64(p + 128 * c + 64 >= lo);
@@ -482,6 +480,83 @@ pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__r
     }
 }
 
+// Candidate-stationary blocks over a JOINT list for a home cell of a staged window: first the row-0 slots from the
+// cell's first home particle to the end of the cell above (row-0 arrays, from slot r0), then the merged candidates
+// [c_lo, c_hi).  Home particle hp (a row-0 slot) pairs with list indices from hp - r0 + 1 on: the later slots of its
+// own cell, the cell above, and every merged candidate (main.c:215-221 and the 13 offsets).  That rule is a shift of
+// the compare masks on the scalar unit, and only in the first block (a window holds at most PC_G_CAPH row-0 slots).
+template <int PAIRS, int MASKED>   // MASKED: how many of the block's leading 64-candidate parts hold slots of the home cell itself
+__device__ __forceinline__ uint32_t pc_g_joint_chunk(const pc_group_lds &L, uint32_t p0, uint32_t n_r0, uint32_t total,
+                                                     uint32_t r0, uint32_t c_lo, uint32_t h_hi, int lane, float d2max)
+{
+    static_assert(offsetof(pc_group_lds, hx) == 3 * PC_G_CAPM * sizeof(float), "row-0 arrays follow the merged ones");
+    const float *all = L.x;                                  // every array of the block as one
+    pc_v2f x[PAIRS], y[PAIRS], z[PAIRS];
+    const float never = __builtin_nanf("");                  // a slot behind the list never matches: no mask per home particle
+#pragma unroll
+    for (int c = 0; c < PAIRS; c++) {
+        float cx[2], cy[2], cz[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t v = p0 + 128 * c + 64 * u + lane;
+            const uint32_t vv = min(v, total - 1);
+            const bool in_r0 = vv < n_r0;
+            const uint32_t at = in_r0 ? 3 * PC_G_CAPM + r0 + vv : c_lo + (vv - n_r0);
+            const uint32_t stride = in_r0 ? PC_G_CAPH : PC_G_CAPM;
+            cx[u] = v < total ? all[at] : never;
+            cy[u] = all[at + stride];
+            cz[u] = all[at + 2 * stride];
+        }
+        x[c] = pc_v2f{cx[0], cx[1]};
+        y[c] = pc_v2f{cy[0], cy[1]};
+        z[c] = pc_v2f{cz[0], cz[1]};
+    }
+    uint32_t hits = 0;
+    for (uint32_t hp = r0; hp < h_hi; hp++) {
+        const float hx = L.hx[hp], hy = L.hy[hp], hz = L.hz[hp];
+        const pc_v2f ax = {hx, hx}, ay = {hy, hy}, az = {hz, hz};
+#pragma unroll
+        for (int c = 0; c < PAIRS; c++) {
+            const pc_v2f dx = ax - x[c], dy = ay - y[c], dz = az - z[c];
+            const pc_v2f sq = (dx * dx + dy * dy) + dz * dz;
+            unsigned long long b0 = __builtin_amdgcn_ballot_w64(sq.x <= d2max);
+            unsigned long long b1 = __builtin_amdgcn_ballot_w64(sq.y <= d2max);
+            // (p0 = 0) lanes below hp - r0 + 1 - 128 c - 64 u are at or before hp
+            if (2 * c < MASKED) {
+                const uint32_t lo = hp - r0 + 1, d0 = lo > 128u * c ? lo - 128u * c : 0u;
+                b0 = d0 >= 64 ? 0ull : b0 & (~0ull << d0);
+            }
+            if (2 * c + 1 < MASKED) {
+                const uint32_t lo = hp - r0 + 1, d1 = lo > 128u * c + 64u ? lo - 128u * c - 64u : 0u;
+                b1 = d1 >= 64 ? 0ull : b1 & (~0ull << d1);
+            }
+            hits += __popcll(b0) + __popcll(b1);
+        }
+    }
+    return hits;
+}
+
+// home particles [r0, h_hi) of one cell of a staged window against row-0 slots [r0, r0_end) and merged candidates [c_lo, c_hi)
+__device__ __forceinline__ uint32_t pc_g_joint(const pc_group_lds &L, uint32_t r0, uint32_t h_hi, uint32_t r0_end,
+                                               uint32_t c_lo, uint32_t c_hi, int lane, float d2max)
+{
+    r0 = __builtin_amdgcn_readfirstlane(r0); h_hi = __builtin_amdgcn_readfirstlane(h_hi);
+    c_lo = __builtin_amdgcn_readfirstlane(c_lo);
+    const uint32_t n_r0 = __builtin_amdgcn_readfirstlane(r0_end - r0);
+    const uint32_t total = n_r0 + __builtin_amdgcn_readfirstlane(c_hi - c_lo);
+    uint32_t hits = 0, p0 = 0;
+    const bool two = h_hi - r0 > 64;                           // the cell's own slots reach into the second 64 candidates
+    if (total > 128)
+        hits += two ? pc_g_joint_chunk<2, 2>(L, 0, n_r0, total, r0, c_lo, h_hi, lane, d2max)
+                    : pc_g_joint_chunk<2, 1>(L, 0, n_r0, total, r0, c_lo, h_hi, lane, d2max);
+    else
+        hits += two ? pc_g_joint_chunk<1, 2>(L, 0, n_r0, total, r0, c_lo, h_hi, lane, d2max)
+                    : pc_g_joint_chunk<1, 1>(L, 0, n_r0, total, r0, c_lo, h_hi, lane, d2max);
+    for (p0 = 256; p0 + 128 < total; p0 += 256) hits += pc_g_joint_chunk<2, 0>(L, p0, n_r0, total, r0, c_lo, h_hi, lane, d2max);
+    if (p0 < total) hits += pc_g_joint_chunk<1, 0>(L, p0, n_r0, total, r0, c_lo, h_hi, lane, d2max);
+    return hits;
+}
+
 // One home cell against its whole neighbourhood, the candidates going through the merged arrays in pieces: home
 // particles [h0, h1) of the sorted array, candidate ranges [c_lo[r], c_hi[r]) -- row 0 from h0 to the end of the cell
 // above, rows 1-4 three cells each.  The five ranges are taken as ONE list, row 0 first (its "later slots only"
@@ -540,7 +615,7 @@ __device__ __forceinline__ uint32_t pc_g_cell(pc_group_lds &L, const float *__re
 // Measurement build only: shader-clock cycles a wave of the group kernel spends in each part of its work, kept in
 // scalar registers and added at the wave's end to one of 64 rows; [row][0..15] cycles, [row][16..31] times.
 // 0 table reads and window bookkeeping, 1 copy into LDS, 2 steps of 2-lane groups, 3 of 4-lane groups, 4 of 8-lane
-// groups, 5 register blocks of a dense window, 6 its same-pencil pairs; a cell that does not fit the buffers: 7 its set-up,
+// groups, 5 register blocks of a dense window; a cell that does not fit the buffers: 7 its set-up,
 // 8 the cell itself (pc_g_cell).
 __device__ unsigned long long pc_g_trace[64][32];
 #define PC_G_MARK(i)                                                      \
@@ -773,30 +848,17 @@ pc_c3_count_groups(const float *__restrict__ pts, const uint32_t *__restrict__ T
                     else if (m3 < 50 * cells) { hits = pc_g_window<4, 8>(L, nh, lane, d2max); PC_G_MARK(3); }
                     else if (m3 < 107 * cells) { hits = pc_g_window<8, 8>(L, nh, lane, d2max); PC_G_MARK(4); }
                     else {
-                        // dense window: per home cell, candidates stay in registers while the
-                        // cell's home particles stream by
+                        // dense window: per home cell, candidates stay in registers while the cell's home
+                        // particles stream by; row 0 and the merged ranges as one list (pc_g_joint)
                         hits = 0;
                         for (int t = th0; t < t_last; t++) {
-                            const uint32_t c_lo = pc_lane_value(lo_m, t), c_hi = pc_lane_value(hi_m, t);
-                            const uint32_t hb = pc_lane_value(ex_h, t), he = hb + pc_lane_value(n[0], t);
-                            hits += pc_g_block<false>(L, c_lo, c_hi, hb, he, lane, d2max);
+                            const uint32_t n0c = pc_lane_value(n[0], t);
+                            if (n0c == 0) continue;
+                            const uint32_t hb = pc_lane_value(ex_h, t);
+                            hits += pc_g_joint(L, hb, hb + n0c, min(pc_lane_value(hi_h, t), (uint32_t)PC_G_CAPH),
+                                               pc_lane_value(lo_m, t), pc_lane_value(hi_m, t), lane, d2max);
                         }
                         PC_G_MARK(5);
-                        // same pencil (the steps above count these themselves): lane per home particle
-                        for (uint32_t hp = lane; hp < nh; hp += 64) {
-                            const float mx = L.hx[hp], my = L.hy[hp], mz = L.hz[hp];
-                            const pc_v2f ax = {mx, mx}, ay = {my, my}, az = {mz, mz};
-                            const uint32_t end = min(L.meta[hp].y, (uint32_t)PC_G_CAPH);    // (an index into the row-0 arrays)
-                            uint32_t cnt = 0;
-                            for (uint32_t k2 = hp + 1; k2 < end; k2 += 2) {       // two candidates per turn
-                                const pc_v2f x = {L.hx[k2], L.hx[k2 + 1]}, y = {L.hy[k2], L.hy[k2 + 1]}, z = {L.hz[k2], L.hz[k2 + 1]};
-                                const pc_v2f dx = ax - x, dy = ay - y, dz = az - z;
-                                const pc_v2f sq = (dx * dx + dy * dy) + dz * dz;
-                                cnt += (sq.x <= d2max) + ((sq.y <= d2max) & (k2 + 1 < end));
-                            }
-                            acc += cnt;
-                        }
-                        PC_G_MARK(6);
                     }
                     if (lane == 0) acc += hits;
                     pc_wave_lds_sync();

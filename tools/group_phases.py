@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 PARTS = ["table reads + window bookkeeping", "copy into LDS (list, DMA, ranges)", "steps, 2-lane groups", "steps, 4-lane groups",
-         "steps, 8-lane groups", "dense window: register blocks", "dense window: same-pencil pairs", "cell that does not fit: set-up",
+         "steps, 8-lane groups", "dense window: register blocks", "(unused)", "cell that does not fit: set-up",
          "  the cell, piece by piece (pc_g_cell)"]
 
 def main():
