@@ -193,6 +193,19 @@ def test_edge_cases(psa, stages, torch_mod, oracle):
                     with pytest.raises(psa.PairCountError):
                         gpu_count(psa, stages, torch_mod, pts, bin_v=1, count_v=cv)
 
+    # the same after a LARGER valid input: the slot the dropped point would have taken now holds a valid point of that
+    # earlier call (some other cell), which no kernel may take for a home particle with ranges of its own
+    big = np.random.default_rng(5).uniform(-9.9, 9.9, (200_000, 3)).astype(np.float32)
+    for cv in (0, 4, 3, 5):
+        for axis in (1, 2, 0):
+            for bad in (10.025, -10.075):
+                assert gpu_count(psa, stages, torch_mod, big, bin_v=1, count_v=cv)[0] == oracle.count_pairs(big)[0]
+                pts = big[:10].copy()
+                pts[7, axis] = bad
+                with pytest.raises(psa.PairCountError):
+                    gpu_count(psa, stages, torch_mod, pts, bin_v=1, count_v=cv)
+    assert gpu_count(psa, stages, torch_mod, big[:1000], bin_v=1, count_v=4)[0] == oracle.count_pairs(big[:1000])[0]
+
 
 def test_finish_reports_a_failure_again(psa, torch_mod, oracle):
     """pc_finish after a failed pc_finish returns the same error, not a count of 0; so do pc_tests and
