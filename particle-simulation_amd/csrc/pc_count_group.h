@@ -82,6 +82,9 @@ __device__ __forceinline__ bool pc_gate_open(const unsigned int *queue, int gate
 // are full there), pc_c3_count_groups<false> if not (measured: the dense kernel loses below about 11 points per cell).
 #define PC_G_SEG_POINTS_DENSE 291
 #define PC_G_SEG_POINTS_THIN 292
+// home pencils the planning kernel has cut into segments: if that is all of them (every pencil of a dense slab holds
+// thousands of points), the merged-window kernel has nothing to do and returns at once instead of visiting each
+#define PC_G_PLANNED_PENCILS 293
 #define PC_SEGS_TO_DENSE 1               // which of the two kernels asks pc_segments_are_dense
 #define PC_SEGS_TO_GROUP 0
 __device__ __forceinline__ bool pc_segment_is_dense(uint32_t points, int cells, uint32_t dense_min)
@@ -437,9 +440,11 @@ pc_c3_plan(const uint32_t *__restrict__ T, int x_lo, int x_hi, unsigned int *__r
         const uint32_t at = base + incl - mine;
         seg_at[lane] = at;
         const int t = blockIdx.x * PC_G_PLAN_PENCILS + lane;
+        const bool cut = t < n_pencils && mine && at + mine <= seg_cap;
         if (t < n_pencils)
-            reinterpret_cast<unsigned char *>(work + PC_G_FLAGS)[(uint32_t)(x_lo + t / PC_NLAYERS) * PC_NBB + t % PC_NLAYERS] =
-                mine && at + mine <= seg_cap;
+            reinterpret_cast<unsigned char *>(work + PC_G_FLAGS)[(uint32_t)(x_lo + t / PC_NLAYERS) * PC_NBB + t % PC_NLAYERS] = cut;
+        const uint32_t n_cut = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(cut));
+        if (lane == 0 && n_cut) atomicAdd(work + PC_G_PLANNED_PENCILS, n_cut);
         if (seg_cap != 0 && __builtin_amdgcn_ballot_w64(mine && at + mine > seg_cap) != 0 && lane == 0) work[PC_G_SEG_OVERFLOW] = 1u;
     }
     __syncthreads();

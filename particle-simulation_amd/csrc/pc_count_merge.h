@@ -233,6 +233,8 @@ pc_c5_count_merged(const float *__restrict__ pts, const uint32_t *__restrict__ T
                    unsigned long long *__restrict__ out, const pc_geom geo, uint32_t dense_min)
 {
     if (!pc_gate_open(queue, gate, gate_limit)) return;
+    // (every home pencil cut into segments by the planning kernel: nothing is left for this kernel)
+    if (__builtin_amdgcn_readfirstlane(queue[PC_G_PLANNED_PENCILS]) == (uint32_t)(x_hi - x_lo) * PC_NLAYERS) return;
     __shared__ pc_merge_lds L;
     const int lane = threadIdx.x;
     unsigned long long acc = 0;          // per-lane partial (lane 0 also carries the wave-uniform hit counts)
